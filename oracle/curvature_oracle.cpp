@@ -1,0 +1,137 @@
+// curvature_oracle.cpp -- CPU ORACLE (test infrastructure): the only consumer of
+// k-nearest in treee: SegmentInformation::update curve branch
+// (treee/src/calculations.rs:328-373) + fast_eigenvalues (:467-498) + map_to_u32 (:455-457).
+// Third-party arithmetic restated from published source, parity unpinned:
+//   nalgebra 0.33.0 (Cargo.lock:1562-1563): Point3 += Vector3, Point3 / f32 (component-wise
+//   true division), Matrix3::determinant (cofactor expansion along the first row);
+//   f32::powi(-3) = compiler-rt __powisf2 / LLVM ExpandPowI = 1 / (p * (p * p)).
+// acos/cos come from the host libm here; Rust uses the platform libm too, but the GPU uses
+// OCML, so `curve` is compared with a tolerance, never bit-exact.
+#include "treee_oracle.h"
+
+#include <cmath>
+#include <thread>
+#include <vector>
+
+namespace {
+
+inline float square(float x) { return x * x; }
+
+// nalgebra Matrix3::determinant, m[r][c]
+inline float det3(const float m[3][3]) {
+	float minor_m12_m23 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+	float minor_m11_m23 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+	float minor_m11_m22 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+	return m[0][0] * minor_m12_m23 - m[0][1] * minor_m11_m23 + m[0][2] * minor_m11_m22;
+}
+
+// calculations.rs:467-498
+void fast_eigenvalues(const float mat[3][3], float out[3]) {
+	float p1 = square(mat[0][1]) + square(mat[0][2]) + square(mat[1][2]);
+	if (p1 == 0.0f) { // :473-476 diagonal returned unsorted
+		out[0] = mat[0][0];
+		out[1] = mat[1][1];
+		out[2] = mat[2][2];
+		return;
+	}
+	float q = (mat[0][0] + mat[1][1] + mat[2][2]) / 3.0f;
+	float p2 = square(mat[0][0] - q) + square(mat[1][1] - q) + square(mat[2][2] - q) + 2.0f * p1;
+	float p = std::sqrt(p2 / 6.0f);
+	float mat_b[3][3];
+	for (int r = 0; r < 3; ++r)
+		for (int c = 0; c < 3; ++c) mat_b[r][c] = mat[r][c];
+	for (int i = 0; i < 3; ++i) mat_b[i][i] -= q;
+	float powi_m3 = 1.0f / (p * (p * p)); // p.powi(-3)
+	float r = det3(mat_b) / 2.0f * powi_m3;
+	const float PI = 3.14159265358979323846f; // std::f32::consts::PI
+	float phi;
+	if (r <= -1.0f)
+		phi = PI / 3.0f;
+	else if (r >= 1.0f)
+		phi = 0.0f;
+	else
+		phi = std::acos(r) / 3.0f;
+	float eig_1 = q + 2.0f * p * std::cos(phi);
+	float eig_3 = q + 2.0f * p * std::cos(phi + (2.0f * PI / 3.0f));
+	float eig_2 = 3.0f * q - eig_1 - eig_3;
+	out[0] = eig_1;
+	out[1] = eig_2;
+	out[2] = eig_3;
+}
+
+// calculations.rs:342-368 for one point, neighbours in returned (ascending) order
+float curve_from(const float *xyz, const orc_entry *nb, uint64_t count) {
+	float len = (float)count; // neighbors.len() as f32
+	float mean[3] = {0.0f, 0.0f, 0.0f};
+	for (uint64_t j = 0; j < count; ++j) { // :344-346
+		const float *p = xyz + 3 * nb[j].index;
+		mean[0] += p[0];
+		mean[1] += p[1];
+		mean[2] += p[2];
+	}
+	mean[0] = mean[0] / len; // :347
+	mean[1] = mean[1] / len;
+	mean[2] = mean[2] / len;
+	float var[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}; // Matrix3::default() = zeros
+	for (uint64_t j = 0; j < count; ++j) { // :351-358
+		const float *p = xyz + 3 * nb[j].index;
+		float diff[3] = {p[0] - mean[0], p[1] - mean[1], p[2] - mean[2]};
+		for (int x = 0; x < 3; ++x)
+			for (int y = 0; y < 3; ++y) var[x][y] += diff[x] * diff[y];
+	}
+	for (int x = 0; x < 3; ++x) // :359-363
+		for (int y = 0; y < 3; ++y) var[x][y] /= len;
+	float eig[3];
+	fast_eigenvalues(var, eig);
+	return (3.0f * eig[2]) / (eig[0] + eig[1] + eig[2]); // :368
+}
+
+} // namespace
+
+extern "C" {
+
+void orc_fast_eigenvalues(const float m[9], float out[3]) {
+	float mat[3][3];
+	for (int r = 0; r < 3; ++r)
+		for (int c = 0; c < 3; ++c) mat[r][c] = m[3 * r + c];
+	fast_eigenvalues(mat, out);
+}
+
+float orc_curve_from_neighbors(const float *xyz, const orc_entry *nb, uint64_t count) {
+	return curve_from(xyz, nb, count);
+}
+
+void orc_curvature(const float *xyz, uint64_t n, uint64_t k, float max_distance, float *curve_out,
+                   int threads) {
+	if (n == 0) return;
+	orc_kdtree *tree = orc_kdtree_new(xyz, n); // NeighborsTree::new (calculations.rs:329)
+	auto work = [&](uint64_t lo, uint64_t hi) {
+		std::vector<orc_entry> loc(k); // neighbors_location, reused (calculations.rs:331)
+		for (uint64_t i = lo; i < hi; ++i) {
+			uint64_t c = orc_kdtree_k_nearest(tree, xyz + 3 * i, loc.data(), k, max_distance);
+			curve_out[i] = curve_from(xyz, loc.data(), c);
+		}
+	};
+	if (threads <= 1) {
+		work(0, n); // as-reference: sequential iterator (calculations.rs:332)
+	} else {
+		std::vector<std::thread> pool;
+		uint64_t per = (n + threads - 1) / threads;
+		for (int th = 0; th < threads; ++th) {
+			uint64_t lo = per * th < n ? per * th : n, hi = lo + per < n ? lo + per : n;
+			if (lo < hi) pool.emplace_back(work, lo, hi);
+		}
+		for (auto &th : pool) th.join();
+	}
+	orc_kdtree_free(tree);
+}
+
+uint32_t orc_map_to_u32(float v) {
+	// (value * u32::MAX as f32) as u32 : Rust `as` saturates, NaN -> 0
+	float x = v * 4294967296.0f; // u32::MAX as f32 rounds to 2^32
+	if (!(x > 0.0f)) return 0;   // negative, zero, NaN
+	if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+	return (uint32_t)x;
+}
+
+} // extern "C"
