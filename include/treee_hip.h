@@ -1,0 +1,198 @@
+/*
+ * treee_hip.h -- C ABI of the MI355X-native treee hot path (libtreee_hip.so).
+ *
+ * The reference (antonWetzel/treee @ 2024_10_08) has no FFI / plugin boundary: every
+ * hot-path call is a monomorphised Rust call.  This header cuts the boundary at the three
+ * narrowest seams of the reference and states, per entry point, the Rust interface it
+ * replaces (file:line relative to the reference root).  INTEGRATION.md shows the Rust
+ * `extern "C"` block + safe wrappers a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int32_t status (TREEE_OK == 0); nothing unwinds across the ABI;
+ *     treee_last_error() returns a thread-local message for the last failure
+ *   - plain pointers and sizes only; no torch / C++ types
+ *   - functions without suffix take HOST pointers (drop-in for the Rust slices they replace:
+ *     they stage through HBM and copy results back)
+ *   - functions with suffix _dev take DEVICE pointers (HBM resident) and a treee_ctx that
+ *     owns the HIP stream and a reusable workspace; they enqueue work on that stream and do
+ *     not synchronise unless documented
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails
+ *     with TREEE_ERR_HIP
+ *   - indices on the device are u32 (<= 2^32-2 points per shard); the host structs widen to
+ *     u64 like Rust's usize
+ */
+#ifndef TREEE_HIP_H
+#define TREEE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TREEE_ABI_VERSION 1
+
+enum {
+	TREEE_OK = 0,
+	TREEE_ERR_INVALID = 1,     /* bad argument (null pointer, k == 0, ...) */
+	TREEE_ERR_HIP = 2,         /* HIP runtime error / no device */
+	TREEE_ERR_EMPTY = 3,       /* KDTree::new on an empty slice panics in the reference */
+	TREEE_ERR_UNSUPPORTED = 4, /* e.g. projection matrix that mixes x/y axes */
+	TREEE_ERR_NOMEM = 5
+};
+
+/* repr(C) mirror of k_nearest::Entry<f32> (k-nearest/src/kd_tree.rs:8-12; the Rust struct is
+ * not repr(C), so the shim converts).  index == UINT64_MAX marks an unused slot. */
+typedef struct {
+	float distance; /* SQUARED euclidean distance (k-nearest/readme.md:90-92) */
+	uint32_t _pad;
+	uint64_t index;
+} treee_entry;
+
+typedef struct treee_ctx treee_ctx;       /* stream + workspace */
+typedef struct treee_knn treee_knn;       /* replaces k_nearest::KDTree<3,f32,..> */
+typedef struct treee_octree treee_octree; /* Morton order + octree + LOD lists */
+
+int32_t treee_abi_version(void);
+const char *treee_last_error(void);
+int32_t treee_device_count(int32_t *count_out);
+
+/* ---- context ------------------------------------------------------------------------- */
+/* hip_stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create one. */
+int32_t treee_ctx_create(int32_t device, void *hip_stream, treee_ctx **out);
+int32_t treee_ctx_destroy(treee_ctx *ctx);
+int32_t treee_ctx_sync(treee_ctx *ctx);
+/* pre-size the workspace so later calls never allocate (benchmarks, graph capture) */
+int32_t treee_ctx_reserve(treee_ctx *ctx, uint64_t bytes);
+
+/* ---- B1: kNN seam -------------------------------------------------------------------- */
+/* KDTree::new(&[Point]) (k-nearest/src/kd_tree.rs:35-42) via NeighborsTree::new
+ * (treee/src/calculations.rs:396-407).  Copies the coordinates; n == 0 -> TREEE_ERR_EMPTY. */
+int32_t treee_knn_build(const float *xyz_aos, uint64_t n, treee_knn **out);
+int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, treee_knn **out);
+int32_t treee_knn_free(treee_knn *t);
+int32_t treee_knn_len(const treee_knn *t, uint64_t *n_out);
+
+/* KDTree::k_nearest / nearest_to_position (kd_tree.rs:82-84,92-96) for nq positions.
+ * out[nq*k] is fully overwritten ("initial values are never read"); counts[nq] receives the
+ * number of valid entries; out[i*k .. i*k+counts[i]) ascending by distance, all distance <
+ * max_dist_sq (strict, squared).  Tie rule: distances and counts are
+ * bit-identical to the reference; among equal distances the entry with the smaller
+ * (morton key, index) wins.  k == 0 -> TREEE_ERR_INVALID (reference panics). */
+int32_t treee_knn_query_batch(const treee_knn *t, const float *q_xyz, uint64_t nq, uint32_t k,
+                              float max_dist_sq, treee_entry *out, uint32_t *counts);
+/* device form: SoA outputs d_dist[nq*k] f32, d_index[nq*k] u32 (0xFFFFFFFF unused),
+ * d_counts[nq] u32.  Any output pointer may be NULL. */
+int32_t treee_knn_query_batch_dev(treee_ctx *ctx, const treee_knn *t, const float *d_q_xyz,
+                                  uint64_t nq, uint32_t k, float max_dist_sq, float *d_dist,
+                                  uint32_t *d_index, uint32_t *d_counts);
+/* every tree point queries itself (the loop of treee/src/calculations.rs:332-340); row i
+ * belongs to original point i */
+int32_t treee_knn_self_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
+                           float *d_dist, uint32_t *d_index, uint32_t *d_counts);
+/* KDTree::nearest (kd_tree.rs:86-90): all points with distance < max_dist_sq, ascending.
+ * Writes min(found, cap) entries, *found_out = total. */
+int32_t treee_knn_radius(const treee_knn *t, const float q_xyz[3], float max_dist_sq,
+                         treee_entry *out, uint64_t cap, uint64_t *found_out);
+/* KDTree::empty (kd_tree.rs:98-102) for nq positions: empty_out[i] = 1 iff no point has
+ * distance < max_dist_sq */
+int32_t treee_knn_empty(const treee_knn *t, const float *q_xyz, uint64_t nq, float max_dist_sq,
+                        uint8_t *empty_out);
+
+/* kNN consumer: SegmentInformation::update curve branch (treee/src/calculations.rs:328-373,
+ * fast_eigenvalues :467-498): curve_out[i] = 3*eig3/(eig1+eig2+eig3) of the covariance of the
+ * k nearest neighbours (reference: k = 31, max_dist_sq = f32::MAX).  acos/cos differ between
+ * libm and OCML: tolerance 1e-5 abs on curve, not bit-exact. */
+int32_t treee_curvature(const float *xyz_aos, uint64_t n, uint32_t k, float max_dist_sq,
+                        float *curve_out);
+int32_t treee_curvature_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
+                            float *d_curve_out);
+/* map_to_u32 (treee/src/calculations.rs:455-457) over a device array */
+int32_t treee_map_to_u32_dev(treee_ctx *ctx, const float *d_in, uint64_t n, uint32_t *d_out);
+
+/* ---- A0: Morton sort + octree + LOD (build-defined; no reference counterpart) -------- */
+/* corner/size: the cube (render/src/camera_3d.rs:20 parametrisation); size <= 0 -> the cube is
+ * computed from the data (min corner, max extent).  leaf_cap / lod_cap 0 -> 256. */
+int32_t treee_sort_build(const float *xyz_aos, uint64_t n, const float corner[3], float size,
+                         uint32_t leaf_cap, uint32_t lod_cap, treee_octree **out);
+int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n,
+                             const float corner[3], float size, uint32_t leaf_cap,
+                             uint32_t lod_cap, treee_octree **out);
+int32_t treee_octree_free(treee_octree *o);
+typedef struct {
+	uint64_t n_points, n_nodes, n_lod;
+	float corner[3], size;
+	uint32_t leaf_cap, lod_cap;
+} treee_octree_info;
+int32_t treee_octree_info_get(const treee_octree *o, treee_octree_info *info);
+/* node record, identical layout on host and device */
+typedef struct {
+	uint32_t key_prefix, level, first, count, first_child, child_mask, parent, lod_first;
+} treee_octree_node;
+enum {
+	TREEE_OCT_KEYS = 0,        /* u32[n]  sorted morton keys */
+	TREEE_OCT_PERM = 1,        /* u32[n]  perm[i] = original index of sorted position i */
+	TREEE_OCT_NODES = 2,       /* treee_octree_node[n_nodes], BFS order */
+	TREEE_OCT_LEAF = 3,        /* u32[n]  leaf node index per sorted position */
+	TREEE_OCT_LOD = 4,         /* u32[n_lod] sorted positions sampled per inner node */
+	TREEE_OCT_SORTED_XYZ = 5   /* float4[n] (x,y,z,bitcast(original index)) in sorted order */
+};
+/* copy an array to host memory (synchronises) */
+int32_t treee_octree_copy(const treee_octree *o, int32_t what, void *dst_host, uint64_t dst_bytes);
+/* raw device pointer of an array (valid until treee_octree_free) */
+int32_t treee_octree_dev_ptr(const treee_octree *o, int32_t what, void **d_ptr_out);
+
+/* ---- B2: splat seam ------------------------------------------------------------------ */
+/* render::PointCloud::new + PointCloudProperty::new + PointCloud::render
+ * (render/src/point_cloud.rs:136-173,183-193) with Camera3DGPU::new (render/src/camera_3d.rs:59)
+ * and PointCloudEnvironment::new (point_cloud.rs:214); shader render/src/point_cloud.wgsl.
+ * view/proj column-major f32[16].  depth_out[w*h] (1.0 = empty), id_out[w*h] = `value` of
+ * the winning point (0 where empty).  proj must not mix x/y (TREEE_ERR_UNSUPPORTED). */
+int32_t treee_splat(const float *xyz_aos, const uint32_t *value, uint64_t n, const float view[16],
+                    const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w,
+                    uint32_t h, float *depth_out, uint32_t *id_out);
+/* d_packed (optional, u64[w*h]) receives (depth_bits << 32 | point index) for cross-GPU
+ * min-reduction; when accumulate != 0 the packed buffer is NOT cleared first and
+ * index_base is added to the point index (multi-chunk / multi-GPU draws). */
+int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz_aos, const uint32_t *d_value, uint64_t n,
+                        const float view[16], const float proj[16], float scale, uint32_t vmin,
+                        uint32_t vmax, uint32_t w, uint32_t h, uint64_t *d_packed,
+                        int32_t accumulate, uint32_t index_base, float *d_depth_out,
+                        uint32_t *d_id_out);
+/* resolve a packed buffer (after a cross-GPU min) into depth + id; d_value indexes by the
+ * low 32 bits */
+int32_t treee_splat_resolve_dev(treee_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_value,
+                                uint64_t n_values, uint32_t w, uint32_t h, float *d_depth_out,
+                                uint32_t *d_id_out);
+/* nalgebra Perspective3::new(aspect,fovy,near,far).to_homogeneous() (camera_3d.rs:16-18) */
+int32_t treee_perspective(float aspect, float fovy, float znear, float zfar, float out[16]);
+/* eye-dome pass (render/src/eye_dome.wgsl:37-67) over a depth buffer; strength is the mapped
+ * uniform (render/src/eye_dome.rs:226-230) */
+int32_t treee_eye_dome_dev(treee_ctx *ctx, const float *d_depth, uint32_t w, uint32_t h,
+                           float strength, float *d_alpha_out);
+
+/* ---- B3: ingest seam ----------------------------------------------------------------- */
+/* Chunk::read / next_point (treee/src/laz.rs:193-213): n records of `stride` bytes whose
+ * first 12 bytes are i32 LE x,y,z -> centred f32 (x, z, -y) */
+int32_t treee_decode_las_records(const uint8_t *rec, uint64_t n, uint32_t stride,
+                                 const double scale[3], const double offset[3],
+                                 const double center[3], float *xyz_out);
+int32_t treee_decode_las_records_dev(treee_ctx *ctx, const uint8_t *d_rec, uint64_t n,
+                                     uint32_t stride, const double scale[3],
+                                     const double offset[3], const double center[3],
+                                     float *d_xyz_out);
+/* loading.rs:99: key = floor(p.y) as isize */
+int32_t treee_slice_keys(const float *xyz_aos, uint64_t n, int64_t *key_out);
+int32_t treee_slice_keys_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, int64_t *d_key_out);
+/* the y-slice map of loading.rs:97-101 densified as segmenting.rs:121-133: order_out[n] =
+ * point indices grouped by slice (arrival order inside a slice), offsets_out[layers+1].
+ * Call with offsets_out == NULL to learn *layers_out / *min_key_out first. */
+int32_t treee_slice_bin(const float *xyz_aos, uint64_t n, int64_t *min_key_out,
+                        uint64_t *layers_out, uint32_t *order_out, uint64_t *offsets_out,
+                        uint64_t offsets_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,337 @@
+"""GPU parity tests proper: every call goes through the C ABI (libtreee_hip.so) and is compared
+with the CPU oracle on the same seeded inputs.  Bit-exact for integer / index / distance
+work; `curve` within 1e-5 (acos/cos: libm vs OCML)."""
+import numpy as np
+import pytest
+
+from conftest import check_knn_contract, f32_dist_sq
+
+pytestmark = pytest.mark.gpu
+
+F32_MAX = float(np.finfo(np.float32).max)
+
+
+@pytest.fixture(scope="module")
+def T():
+    import treee_amd
+
+    treee_amd.lib()
+    return treee_amd
+
+
+def quantised_cloud(n, seed, extent=(100, 30, 100)):
+    rng = np.random.default_rng(seed)
+    p = rng.random((n, 3)) * np.array(extent)
+    return (np.round(p * 1000) / 1000).astype(np.float32)
+
+
+def cube_of(points):
+    mn = points.min(0).astype(np.float32)
+    ext = (points.max(0).astype(np.float32) - mn).astype(np.float32)
+    size = np.float32(ext.max())
+    if not size > 0:
+        size = np.float32(1.0)
+    return mn, float(size)
+
+
+# ---------------------------------------------------------------- A0 sort / octree / LOD
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4095, 4096, 4097, 100_003])
+def test_morton_sort_octree_bit_exact(T, oracle, n):
+    pts = quantised_cloud(n, 100 + n)
+    corner, size = cube_of(pts)
+    oc = T.Octree(pts, corner, size, leaf_cap=64, lod_cap=32)
+    keys = oracle.morton_keys(pts, corner, size)
+    sk, perm = oracle.sort_keys(keys)
+    assert np.array_equal(oc.array("keys"), sk)
+    assert np.array_equal(oc.array("perm"), perm)
+    nodes, leaf, lod = oracle.octree_build(sk, 64, 32)
+    assert oc.n_nodes == len(nodes)
+    got_nodes = oc.array("nodes")
+    for f in nodes.dtype.names:
+        assert np.array_equal(got_nodes[f], nodes[f]), f
+    assert np.array_equal(oc.array("leaf"), leaf)
+    assert np.array_equal(oc.array("lod"), lod)
+    sx = oc.array("sorted_xyz")
+    assert np.array_equal(sx[:, :3], pts[perm])
+    assert np.array_equal(sx[:, 3].view(np.uint32), perm)
+
+
+def test_octree_auto_cube_and_duplicates(T, oracle):
+    pts = quantised_cloud(20_000, 7)
+    pts[5000:9000] = pts[0]  # 4000 duplicates: one deep cell
+    oc = T.Octree(pts, leaf_cap=128, lod_cap=128)  # cube computed on the device
+    corner, size = cube_of(pts)
+    assert np.array_equal(oc.corner, corner) and oc.size == size
+    sk, perm = oracle.sort_keys(oracle.morton_keys(pts, corner, size))
+    assert np.array_equal(oc.array("perm"), perm)
+    nodes, leaf, lod = oracle.octree_build(sk, 128, 128)
+    assert np.array_equal(oc.array("nodes").view(np.uint32), nodes.view(np.uint32))
+    assert np.array_equal(oc.array("leaf"), leaf) and np.array_equal(oc.array("lod"), lod)
+
+
+def test_octree_device_path_and_properties_1m(T, oracle):
+    import torch
+
+    from treee_amd import synth
+
+    pts = synth.uniform_cloud(1_000_000)
+    oc = T.Octree(torch.from_numpy(pts).cuda())
+    keys, perm = oc.array("keys"), oc.array("perm")
+    assert np.all(keys[1:] >= keys[:-1])  # sortedness
+    assert np.array_equal(np.sort(perm), np.arange(len(pts), dtype=np.uint32))  # permutation
+    same = keys[1:] == keys[:-1]
+    assert np.all(perm[1:][same] > perm[:-1][same])  # stability
+    corner, size = cube_of(pts)
+    assert np.array_equal(keys, oracle.morton_keys(pts, corner, size)[perm])
+    nodes = oc.array("nodes")
+    leaves = nodes[nodes["first_child"] == 0xFFFFFFFF]
+    assert leaves["count"].sum() == len(pts)  # leaves tile the cloud
+
+
+# ---------------------------------------------------------------- A1-A4 kNN
+def test_knn_kat_hand_traced(T):
+    # derived by hand from kd_tree.rs / best_set.rs
+    pts = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0]], np.float32)
+    tree = T.KDTree.new(pts)
+    out, count = tree.k_nearest(pts[0], 2, F32_MAX)
+    assert count == 2 and out["distance"].tolist() == [0.0, 1.0] and out["index"].tolist() == [0, 1]
+    out, count = tree.k_nearest(pts[0], 2, 1.0)  # strict `<` excludes d^2 == 1.0
+    assert count == 1 and out["distance"][0] == 0.0 and out["index"][0] == 0
+    assert out["index"][1] == T.INVALID_INDEX
+    assert tree.empty([10, 0, 0], 1.0) and not tree.empty([3.5, 0, 0], 1.0)
+    near = tree.nearest([0, 0, 0], 4.5)
+    assert near["index"].tolist() == [0, 1, 2] and near["distance"].tolist() == [0.0, 1.0, 4.0]
+
+
+def test_knn_errors_mirror_reference_panics(T):
+    with pytest.raises(T.TreeeError) as e:
+        T.KDTree.new(np.zeros((0, 3), np.float32))  # kd_tree.rs:53,60 underflow panic
+    assert e.value.code == 3
+    tree = T.KDTree.new(np.zeros((3, 3), np.float32))
+    with pytest.raises(T.TreeeError):
+        tree.k_nearest([0, 0, 0], 0, 1.0)  # best_set.rs:74 values[0] panic
+
+
+@pytest.mark.parametrize("n,k,maxd", [(1, 31, F32_MAX), (5, 31, F32_MAX), (64, 31, F32_MAX), (65, 8, F32_MAX),
+                                      (5000, 31, F32_MAX), (5000, 31, 0.5625), (5000, 1, F32_MAX), (20_000, 31, F32_MAX),
+                                      (3000, 100, F32_MAX)])
+def test_knn_self_queries_vs_reference_kdtree(T, oracle, n, k, maxd):
+    pts = quantised_cloud(n, 1000 + n + k, extent=(20, 6, 20))
+    ref = oracle.KDTree(pts)
+    r_ent, r_cnt = ref.k_nearest_batch(pts, k, maxd)
+    tree = T.KDTree.new(pts)
+    g_ent, g_cnt = tree.k_nearest_batch(pts, k, maxd)
+    check_knn_contract(pts, pts, g_ent, g_cnt, r_ent, r_cnt)
+    if maxd == F32_MAX:  # readme.md:26-34: offset 0 is the query point itself
+        assert np.all(g_ent["distance"][:, 0] == 0.0)
+    for i in range(0, n, max(1, n // 50)):
+        c = g_cnt[i]
+        d = g_ent["distance"][i][:c]
+        assert np.all(d[1:] >= d[:-1]) and np.all(d < maxd)
+        assert np.all(g_ent["index"][i][c:] == T.INVALID_INDEX)
+
+
+def test_knn_external_queries_and_ties(T, oracle):
+    # integer lattice: massive exact ties in squared distance
+    g = np.arange(12, dtype=np.float32)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(5)
+    q = np.concatenate([pts[rng.integers(0, len(pts), 300)], rng.random((300, 3)).astype(np.float32) * 14 - 1])
+    ref = oracle.KDTree(pts)
+    r_ent, r_cnt = ref.k_nearest_batch(q, 31, F32_MAX)
+    tree = T.KDTree.new(pts)
+    g_ent, g_cnt = tree.k_nearest_batch(q, 31, F32_MAX)
+    ndiff = check_knn_contract(pts, q, g_ent, g_cnt, r_ent, r_cnt)
+    assert ndiff > 0  # the tie rule really differs from KD-tree visit order on a lattice
+    # canonical order (distance, morton key, index): bit-exact incl. indices
+    corner, size = cube_of(pts)
+    keys = oracle.morton_keys(pts, corner, size).astype(np.uint64)
+    for i in range(0, len(q), 17):
+        d = f32_dist_sq(pts, q[i]).view(np.uint32).astype(np.uint64)
+        order = np.lexsort((np.arange(len(pts)), keys, d))[:31]
+        assert np.array_equal(g_ent["index"][i], order.astype(np.uint64)), i
+
+
+def test_knn_deterministic_and_device_path(T, oracle):
+    import torch
+
+    pts = quantised_cloud(30_000, 42, extent=(30, 10, 30))
+    d_pts = torch.from_numpy(pts).cuda()
+    tree = T.KDTree.new(d_pts)
+    d1, i1, c1 = tree.self_neighbors_dev(31)
+    d2, i2, c2 = tree.self_neighbors_dev(31)
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d2) and torch.equal(i1, i2) and torch.equal(c1, c2)
+    ref = oracle.KDTree(pts)
+    r_ent, r_cnt = ref.k_nearest_batch(pts, 31, F32_MAX)
+    g = np.zeros((len(pts), 31), T.ENTRY_DTYPE)
+    g["distance"] = d1.cpu().numpy()
+    g["index"] = i1.cpu().numpy().view(np.uint32)
+    check_knn_contract(pts, pts, g, c1.cpu().numpy(), r_ent, r_cnt)
+    qd, qi, qc = tree.k_nearest_dev(d_pts[:1000], 31)
+    assert torch.equal(qd, d1[:1000]) and torch.equal(qi, i1[:1000])
+
+
+def test_knn_radius_and_empty_vs_reference(T, oracle):
+    pts = quantised_cloud(8000, 77, extent=(10, 10, 10))
+    ref = oracle.KDTree(pts)
+    tree = T.KDTree.new(pts)
+    rng = np.random.default_rng(3)
+    for q in rng.random((20, 3)).astype(np.float32) * 12 - 1:
+        a, b = tree.nearest(q, 1.5), ref.nearest(q, 1.5)
+        assert np.array_equal(a["distance"], b["distance"])
+        assert np.array_equal(np.sort(a["index"]), np.sort(b["index"]))
+        for r in (0.01, 0.2, 4.0):
+            assert tree.empty(q, r) == ref.empty(q, r)
+
+
+# ---------------------------------------------------------------- A5 curvature
+def test_curvature_vs_oracle(T, oracle):
+    from treee_amd import synth
+
+    pts, _ = synth.forest_cloud(40_000, plot=12.0)
+    ref = oracle.curvature(pts, 31, F32_MAX, threads=8)
+    got = T.curvature(pts, 31, F32_MAX)
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    # exact-tie neighbourhoods may sum in another order (H2) and acos/cos differ (H3)
+    assert np.max(np.abs(got[~nan] - ref[~nan])) < 1e-4
+    assert np.mean(np.abs(got[~nan] - ref[~nan]) < 1e-5) > 0.999
+
+
+def test_curvature_tie_free_cloud_tight_tolerance(T, oracle):
+    rng = np.random.default_rng(9)
+    pts = rng.random((20_000, 3)).astype(np.float32) * np.float32(25)  # full-mantissa: no distance ties
+    ref = oracle.curvature(pts, 31, F32_MAX, threads=8)
+    got = T.curvature(pts, 31, F32_MAX)
+    assert np.max(np.abs(got - ref)) < 1e-5
+    u = T.map_to_u32_dev(__import__("torch").from_numpy(got).cuda()).cpu().numpy().view(np.uint32)
+    assert u.tolist()[:50] == [oracle.map_to_u32(v) for v in got[:50]]
+
+
+# ---------------------------------------------------------------- A6-A7 splat
+def default_camera(T, w, h):
+    cam = T.Camera3D(w / h)
+    view = T.view_from_transform(T.translation(0.0, 0.0, 100.0))  # treee/src/camera.rs:28
+    return view, cam.projection()
+
+
+def test_perspective_matches_oracle(T, oracle):
+    assert np.array_equal(T.Camera3D(16 / 9).projection(), oracle.perspective(16 / 9, T.render.FIELD_OF_VIEW, 0.1, 10_000.0))
+
+
+@pytest.mark.parametrize("scale,transform", [(0.1, "default"), (1.0, "default"), (0.5, "topdown"), (0.3, "inside")])
+def test_splat_bit_exact_vs_software_rasteriser(T, oracle, scale, transform):
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(150_000, plot=40.0)
+    w, h = 320, 180
+    cam = T.Camera3D(w / h)
+    tf = {
+        "default": T.translation(0, 0, 100.0),
+        "topdown": T.rotation_x(-np.pi / 2) @ T.translation(0, 0, 60.0),
+        "inside": T.translation(0, 5.0, 3.0),  # camera inside the cloud: huge splats, near clipping
+    }[transform]
+    view, proj = T.view_from_transform(tf), cam.projection()
+    env = T.PointCloudEnvironment(0, 0xFFFFFFFF, scale)
+    depth, ids = T.PointCloud(pts).render(T.PointCloudProperty(seg), view, proj, env, w, h)
+    rd, ri, _ = oracle.splat(pts, seg, view, proj, scale, 0, 0xFFFFFFFF, w, h)
+    assert np.array_equal(depth.view(np.uint32), rd.view(np.uint32))
+    assert np.array_equal(ids, ri)
+    assert (depth < 1.0).sum() > 100
+
+
+def test_splat_value_cull_ties_and_device_path(T, oracle):
+    import torch
+
+    w, h = 64, 48
+    view, proj = default_camera(T, w, h)
+    # two coincident points: first drawn wins; third is culled by the value range
+    pts = np.array([[0, 0, 0], [0, 0, 0], [0.5, 0, 10.0]], np.float32)
+    val = np.array([7, 9, 100], np.uint32)
+    env = T.PointCloudEnvironment(0, 50, 2.0)
+    depth, ids = T.PointCloud(pts).render(T.PointCloudProperty(val), view, proj, env, w, h)
+    rd, ri, _ = oracle.splat(pts, val, view, proj, 2.0, 0, 50, w, h)
+    assert np.array_equal(depth, rd) and np.array_equal(ids, ri)
+    assert set(np.unique(ids)) == {0, 7}
+    d2, i2 = T.PointCloud(torch.from_numpy(pts).cuda()).render(
+        T.PointCloudProperty(torch.from_numpy(val.view(np.int32)).cuda()), view, proj, env, w, h)
+    assert np.array_equal(d2.cpu().numpy(), rd) and np.array_equal(i2.cpu().numpy().view(np.uint32), ri)
+    ed = T.eye_dome_dev(d2, 0.7).cpu().numpy()
+    assert np.array_equal(ed, oracle.eye_dome(rd, max(1 - 0.7, 0.1) ** 6))
+    with pytest.raises(T.TreeeError):
+        bad = proj.copy()
+        bad[4] = 0.1
+        T.PointCloud(pts).render(T.PointCloudProperty(val), view, bad, env, w, h)
+
+
+# ---------------------------------------------------------------- A8-A9 ingest
+@pytest.mark.parametrize("stride,fmt", [(20, 0), (28, 1), (26, 2), (34, 3)])
+def test_las_decode_bit_exact(T, oracle, stride, fmt):
+    from treee_amd import synth
+
+    rng = np.random.default_rng(stride)
+    ints = rng.integers(-2_000_000_000, 2_000_000_000, (120_001, 3)).astype(np.int32)
+    ints[:4] = [[0, 0, 0], [2147483647, -2147483648, 1], [-1, -1, -1], [123456, 654321, -42]]
+    img = synth.las_bytes(ints, scale=(0.001, 0.002, 0.0005), offset=(500000.25, 4.5e6, 120.125), fmt=fmt, record_length=stride)
+    laz = T.Laz(img)
+    hdr = oracle.las_header_parse(img)
+    assert laz.header.number_of_point_records == hdr.number_of_point_records == len(ints)
+    assert np.array_equal(laz.center, np.array(list(hdr.center)))
+    assert laz.total() == 3  # 50 000-point pseudo-chunks (laz.rs:96-107)
+    chunks = []
+    laz.read(lambda c: chunks.append(c.read()))
+    got = np.concatenate(chunks)
+    ref = oracle.decode_las_records(img[hdr.offset_to_point_data:], len(ints), stride, list(hdr.scale), list(hdr.offset), list(hdr.center))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(T.CorruptFile):
+        T.Laz(b"LASX" + img[4:])
+
+
+def test_slice_keys_and_binning(T, oracle):
+    from treee_amd import synth
+
+    pts, _ = synth.forest_cloud(200_000, plot=30.0)
+    pts[:5, 1] = [-0.0, -0.5, 29.999, np.nan, -3.0000002]
+    assert np.array_equal(T.slice_keys(pts), oracle.slice_keys(pts))
+    mn, order, offsets = T.slice_bin(pts)
+    rmn, rorder, roffsets = oracle.slice_bin(pts)
+    assert mn == rmn and np.array_equal(offsets, roffsets) and np.array_equal(order.astype(np.uint64), rorder)
+
+
+# ---------------------------------------------------------------- full-size properties (cfg 2/3)
+def test_full_size_15m_properties(T, oracle):
+    """BASELINE.json configs[1]/[2] size: size-independent properties + sampled exact checks."""
+    import torch
+
+    from treee_amd import synth
+
+    n = 15_000_000
+    d_pts, d_seg = synth.forest_cloud_torch(n, "cuda")
+    oc = T.Octree(d_pts)
+    keys, perm = oc.array("keys"), oc.array("perm")
+    assert np.all(keys[1:] >= keys[:-1])
+    assert np.bincount(perm, minlength=n).max() == 1
+    nodes = oc.array("nodes")
+    leaves = nodes[nodes["first_child"] == 0xFFFFFFFF]
+    assert leaves["count"].sum() == n
+    oc.close()
+    tree = T.KDTree.new(d_pts)
+    dist, index, counts = tree.self_neighbors_dev(31)
+    torch.cuda.synchronize()
+    assert int(counts.min()) == 31 and int(counts.max()) == 31
+    assert bool((dist[:, 0] == 0).all())
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    # sampled brute force over all 15 M points, exact op order, on the GPU via torch
+    sample = torch.randint(0, n, (48,), generator=torch.Generator().manual_seed(1)).cuda()
+    for s in sample.tolist():
+        q = d_pts[s]
+        dx, dy, dz = d_pts[:, 0] - q[0], d_pts[:, 1] - q[1], d_pts[:, 2] - q[2]
+        d = (dx * dx + dy * dy) + dz * dz
+        ref = torch.topk(d, 31, largest=False).values
+        assert torch.equal(torch.sort(ref).values, dist[s]), s
+    pts = d_pts[:300_000].cpu().numpy()  # one spatially mixed subset against the oracle KD-tree
+    sub = T.KDTree.new(pts)
+    g_ent, g_cnt = sub.k_nearest_batch(pts[:20_000], 31, F32_MAX)
+    r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts[:20_000], 31, F32_MAX, threads=8)
+    check_knn_contract(pts, pts[:20_000], g_ent, g_cnt, r_ent, r_cnt)

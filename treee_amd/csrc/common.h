@@ -1,0 +1,144 @@
+// common.h -- internals shared by the HIP translation units of libtreee_hip.so.
+// gfx950 (CDNA4) only: wave = 64 lanes, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/treee_hip.h"
+
+namespace treee {
+
+constexpr int WAVE = 64;
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+
+// ---- errors ---------------------------------------------------------------------------
+int32_t set_err(int32_t code, const char *fmt, ...);
+#define TREEE_HIP(expr)                                                                          \
+	do {                                                                                         \
+		hipError_t e__ = (expr);                                                                 \
+		if (e__ != hipSuccess)                                                                   \
+			return ::treee::set_err(TREEE_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+			                        hipGetErrorString(e__), __FILE__, __LINE__);                \
+	} while (0)
+#define TREEE_TRY(expr)                                                                          \
+	do {                                                                                         \
+		int32_t rc__ = (expr);                                                                   \
+		if (rc__ != TREEE_OK) return rc__;                                                       \
+	} while (0)
+#define TREEE_LAUNCH_CHECK() TREEE_HIP(hipGetLastError())
+
+inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---- device helpers --------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// inclusive wave scan (64 lanes) of u32
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+	const int lane = lane_id();
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		uint32_t t = __shfl_up(v, o, 64);
+		if (lane >= o) v += t;
+	}
+	return v;
+}
+
+// exclusive block scan for blockDim.x == 256 (4 waves); `part` = 4 u32 of LDS scratch.
+// Returns exclusive prefix; *total (optional) receives the block sum.  Contains barriers.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *part, uint32_t *total) {
+	const int lane = lane_id(), w = threadIdx.x >> 6;
+	uint32_t inc = wave_incl_scan(v);
+	if (lane == 63) part[w] = inc;
+	__syncthreads();
+	uint32_t base = 0, sum = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		uint32_t p = part[i];
+		if (i < w) base += p;
+		sum += p;
+	}
+	__syncthreads();
+	if (total) *total = sum;
+	return base + inc - v;
+}
+
+} // namespace treee
+
+// ---- context -----------------------------------------------------------------------------
+struct treee_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	// workspace arena: bump allocation inside blocks; reset at the start of every API call.
+	struct Block {
+		char *p;
+		size_t cap;
+	};
+	std::vector<Block> blocks;
+	size_t cur = 0; // block index
+	size_t off = 0; // offset in blocks[cur]
+	int num_cus = 256;
+
+	int32_t reset();                         // start of an API call: coalesce + rewind
+	int32_t alloc(size_t bytes, void **out); // 256-B aligned
+	template <class T> int32_t alloc_t(size_t count, T **out) {
+		void *p = nullptr;
+		int32_t rc = alloc(count * sizeof(T), &p);
+		*out = (T *)p;
+		return rc;
+	}
+};
+
+namespace treee {
+
+// ---- internal stage entry points (device pointers, enqueue on ctx->stream) ---------------
+// radix_sort.hip
+int32_t morton_keys_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3],
+                        float size, uint32_t *d_keys);
+// sorts (key,val) pairs by the low `bits` bits of key, stable.  d_vals_in == nullptr means
+// val = index.  Results land in d_keys_out / d_vals_out; tmp buffers come from the arena.
+int32_t sort_pairs_dev(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in,
+                       uint64_t n, int bits, uint32_t *d_keys_out, uint32_t *d_vals_out);
+int32_t bbox_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, float corner_out[3],
+                 float *size_out); // synchronises
+int32_t gather_sorted_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_perm, uint64_t n,
+                          float4 *d_sorted);
+int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n,
+                               uint32_t *d_total /* device, optional */);
+
+// common per-cloud preparation shared by octree and knn: cube, keys, sort, gather
+struct SortedCloud {
+	uint64_t n = 0;
+	float corner[3] = {0, 0, 0};
+	float size = 0;
+	uint32_t *d_keys = nullptr;  // sorted
+	uint32_t *d_perm = nullptr;  // sorted position -> original index
+	float4 *d_sorted = nullptr;  // (x,y,z,bitcast(orig)) sorted
+	void release();
+};
+int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner,
+                           float size, SortedCloud *out);
+
+// default context for the host-pointer API (created lazily, one per process)
+int32_t default_ctx(treee_ctx **out);
+
+template <class T> struct DevBuf { // RAII for hipMalloc'd temporaries in host wrappers
+	T *p = nullptr;
+	~DevBuf() {
+		if (p) (void)hipFree(p);
+	}
+	int32_t alloc(size_t count) {
+		if (count == 0) count = 1;
+		hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+		if (e != hipSuccess) return set_err(TREEE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
+		return TREEE_OK;
+	}
+};
+
+} // namespace treee

@@ -1,0 +1,159 @@
+// context.hip -- error state, treee_ctx (stream + workspace arena), default context.
+#include "common.h"
+
+#include <mutex>
+
+namespace treee {
+
+static thread_local char g_err[512] = "";
+
+int32_t set_err(int32_t code, const char *fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+static std::mutex g_default_mu;
+static treee_ctx *g_default = nullptr;
+
+int32_t default_ctx(treee_ctx **out) {
+	std::lock_guard<std::mutex> lk(g_default_mu);
+	if (!g_default) {
+		int dev = 0;
+		TREEE_HIP(hipGetDevice(&dev));
+		TREEE_TRY(treee_ctx_create(dev, nullptr, &g_default));
+	}
+	*out = g_default;
+	return TREEE_OK;
+}
+
+} // namespace treee
+
+using namespace treee;
+
+int32_t treee_ctx::reset() {
+	// coalesce into one block if the previous call had to chain several
+	if (blocks.size() > 1) {
+		size_t total = 0;
+		for (auto &b : blocks) total += b.cap;
+		TREEE_HIP(hipStreamSynchronize(stream));
+		for (auto &b : blocks) (void)hipFree(b.p);
+		blocks.clear();
+		char *p = nullptr;
+		hipError_t e = hipMalloc((void **)&p, total);
+		if (e != hipSuccess) return set_err(TREEE_ERR_NOMEM, "workspace hipMalloc(%zu): %s", total, hipGetErrorString(e));
+		blocks.push_back({p, total});
+	}
+	cur = 0;
+	off = 0;
+	return TREEE_OK;
+}
+
+int32_t treee_ctx::alloc(size_t bytes, void **out) {
+	bytes = (bytes + 255) & ~size_t(255);
+	if (bytes == 0) bytes = 256;
+	while (cur < blocks.size()) {
+		if (off + bytes <= blocks[cur].cap) {
+			*out = blocks[cur].p + off;
+			off += bytes;
+			return TREEE_OK;
+		}
+		cur++;
+		off = 0;
+	}
+	size_t cap = bytes < (size_t(64) << 20) ? (size_t(64) << 20) : bytes;
+	char *p = nullptr;
+	hipError_t e = hipMalloc((void **)&p, cap);
+	if (e != hipSuccess) return set_err(TREEE_ERR_NOMEM, "workspace hipMalloc(%zu): %s", cap, hipGetErrorString(e));
+	blocks.push_back({p, cap});
+	cur = blocks.size() - 1;
+	*out = p;
+	off = bytes;
+	return TREEE_OK;
+}
+
+extern "C" {
+
+int32_t treee_abi_version(void) { return TREEE_ABI_VERSION; }
+
+const char *treee_last_error(void) { return g_err; }
+
+int32_t treee_device_count(int32_t *count_out) {
+	if (!count_out) return set_err(TREEE_ERR_INVALID, "count_out is null");
+	int c = 0;
+	hipError_t e = hipGetDeviceCount(&c);
+	if (e != hipSuccess) {
+		*count_out = 0;
+		return set_err(TREEE_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+	}
+	*count_out = c;
+	return TREEE_OK;
+}
+
+int32_t treee_ctx_create(int32_t device, void *hip_stream, treee_ctx **out) {
+	if (!out) return set_err(TREEE_ERR_INVALID, "out is null");
+	*out = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count == 0)
+		return set_err(TREEE_ERR_HIP, "no HIP device available (%s); libtreee_hip has no CPU fallback",
+		               e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+	if (device < 0 || device >= count) return set_err(TREEE_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+	TREEE_HIP(hipSetDevice(device));
+	treee_ctx *c = new treee_ctx;
+	c->device = device;
+	if (hip_stream) {
+		c->stream = (hipStream_t)hip_stream;
+		c->own_stream = false;
+	} else {
+		hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+		if (se != hipSuccess) {
+			delete c;
+			return set_err(TREEE_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
+		}
+		c->own_stream = true;
+	}
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+	*out = c;
+	return TREEE_OK;
+}
+
+int32_t treee_ctx_destroy(treee_ctx *ctx) {
+	if (!ctx) return TREEE_OK;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	for (auto &b : ctx->blocks) (void)hipFree(b.p);
+	if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return TREEE_OK;
+}
+
+int32_t treee_ctx_sync(treee_ctx *ctx) {
+	if (!ctx) return set_err(TREEE_ERR_INVALID, "ctx is null");
+	TREEE_HIP(hipStreamSynchronize(ctx->stream));
+	return TREEE_OK;
+}
+
+int32_t treee_ctx_reserve(treee_ctx *ctx, uint64_t bytes) {
+	if (!ctx) return set_err(TREEE_ERR_INVALID, "ctx is null");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	size_t have = 0;
+	for (auto &b : ctx->blocks) have += b.cap;
+	if (have >= bytes && ctx->blocks.size() == 1) return TREEE_OK;
+	TREEE_HIP(hipStreamSynchronize(ctx->stream));
+	for (auto &b : ctx->blocks) (void)hipFree(b.p);
+	ctx->blocks.clear();
+	char *p = nullptr;
+	size_t cap = bytes > have ? bytes : have;
+	hipError_t e = hipMalloc((void **)&p, cap);
+	if (e != hipSuccess) return set_err(TREEE_ERR_NOMEM, "workspace hipMalloc(%zu): %s", cap, hipGetErrorString(e));
+	ctx->blocks.push_back({p, cap});
+	ctx->cur = 0;
+	ctx->off = 0;
+	return TREEE_OK;
+}
+
+} // extern "C"

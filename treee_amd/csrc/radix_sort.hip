@@ -1,0 +1,389 @@
+// radix_sort.hip -- Morton key generation, LSD radix sort (8-bit digits, LDS digit bins,
+// wave64 ballot ranking), exclusive scan, cube reduction, sorted gather.
+//
+// Build-defined stage: the reference has no Morton / sort code;
+// the only reference hook is the cube (corner,size) of render/src/camera_3d.rs:20-51.  The
+// GPU analogue of the y-slice binning (treee/src/loading.rs:97-101) reuses the same sort.
+// Bit-exact against oracle/octree_oracle.cpp (stable sort by key, ties by original index).
+//
+// Sort structure per 8-bit pass (all HBM-bound, integer only):
+//   rs_hist      read keys                     -> table[digit][tile]          4 B/key
+//   rs_scan_rows exclusive scan of each digit row, digit totals               (tiny)
+//   rs_scatter   read key+val, rank in-tile with 8 wave ballots per key (match-any on the
+//                digit), stage the tile sorted by digit in LDS, write runs    16 B/key
+#include "common.h"
+
+namespace treee {
+
+constexpr int RS_BLOCK = 256;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_BLOCK * RS_ITEMS; // 4096 keys per workgroup
+
+// ---- Morton keys -------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quant10(float p, float c, float size) {
+	float t = ((p - c) / size) * 1024.0f; // IEEE divide (hipcc default is correctly rounded)
+	if (!(t >= 0.0f)) return 0u;          // negative or NaN
+	if (t >= 1024.0f) return 1023u;
+	return (uint32_t)t;
+}
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {
+	v &= 0x3FFu;
+	v = (v | (v << 16)) & 0x030000FFu;
+	v = (v | (v << 8)) & 0x0300F00Fu;
+	v = (v | (v << 4)) & 0x030C30C3u;
+	v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ xyz, uint32_t n,
+                                                      float cx, float cy, float cz, float size,
+                                                      uint32_t *__restrict__ keys) {
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	float x = xyz[3ull * i + 0], y = xyz[3ull * i + 1], z = xyz[3ull * i + 2];
+	keys[i] = spread3(quant10(x, cx, size)) | (spread3(quant10(y, cy, size)) << 1) |
+	          (spread3(quant10(z, cz, size)) << 2);
+}
+
+int32_t morton_keys_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3],
+                        float size, uint32_t *d_keys) {
+	if (n == 0) return TREEE_OK;
+	hipLaunchKernelGGL(k_morton_keys, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_xyz,
+	                   (uint32_t)n, corner[0], corner[1], corner[2], size, d_keys);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+// ---- cube (bounding box) -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bbox_partial(const float *__restrict__ xyz, uint32_t n,
+                                                       float *__restrict__ partial /*[grid][6]*/) {
+	float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			float v = xyz[3ull * i + a];
+			mn[a] = fminf(mn[a], v);
+			mx[a] = fmaxf(mx[a], v);
+		}
+	}
+	__shared__ float s[4][6];
+#pragma unroll
+	for (int a = 0; a < 3; ++a) {
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			mn[a] = fminf(mn[a], __shfl_down(mn[a], o, 64));
+			mx[a] = fmaxf(mx[a], __shfl_down(mx[a], o, 64));
+		}
+	}
+	if (lane_id() == 0) {
+		for (int a = 0; a < 3; ++a) {
+			s[threadIdx.x >> 6][a] = mn[a];
+			s[threadIdx.x >> 6][3 + a] = mx[a];
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 6) {
+		float v = s[0][threadIdx.x];
+		for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+		partial[blockIdx.x * 6 + threadIdx.x] = v;
+	}
+}
+
+int32_t bbox_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, float corner_out[3], float *size_out) {
+	uint32_t grid = n < 256 * 1024 ? div_up(n ? n : 1, 256) : 1024;
+	float *d_partial = nullptr;
+	TREEE_TRY(ctx->alloc_t(grid * 6, &d_partial));
+	hipLaunchKernelGGL(k_bbox_partial, dim3(grid), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, d_partial);
+	TREEE_LAUNCH_CHECK();
+	std::vector<float> h(grid * 6);
+	TREEE_HIP(hipMemcpyAsync(h.data(), d_partial, grid * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	TREEE_HIP(hipStreamSynchronize(ctx->stream));
+	float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+	for (uint32_t b = 0; b < grid; ++b)
+		for (int a = 0; a < 3; ++a) {
+			mn[a] = fminf(mn[a], h[b * 6 + a]);
+			mx[a] = fmaxf(mx[a], h[b * 6 + 3 + a]);
+		}
+	float size = 0.0f;
+	for (int a = 0; a < 3; ++a) {
+		corner_out[a] = mn[a];
+		float e = mx[a] - mn[a];
+		if (e > size) size = e;
+	}
+	if (!(size > 0.0f) || !(size < INFINITY)) size = 1.0f;
+	for (int a = 0; a < 3; ++a)
+		if (!(corner_out[a] > -INFINITY && corner_out[a] < INFINITY)) corner_out[a] = 0.0f;
+	*size_out = size;
+	return TREEE_OK;
+}
+
+// ---- radix sort ----------------------------------------------------------------------------
+__global__ __launch_bounds__(RS_BLOCK) void rs_hist(const uint32_t *__restrict__ keys, uint32_t n,
+                                                    int shift, uint32_t *__restrict__ table,
+                                                    uint32_t ntiles) {
+	__shared__ uint32_t h[4][256]; // one digit-bin set per wave: conflicts stay inside a wave
+	const int tid = threadIdx.x, w = tid >> 6;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) h[i][tid] = 0;
+	__syncthreads();
+	const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; ++i) {
+		uint32_t idx = base + i * RS_BLOCK + tid;
+		if (idx < n) atomicAdd(&h[w][(keys[idx] >> shift) & 255u], 1u);
+	}
+	__syncthreads();
+	table[(uint32_t)tid * ntiles + blockIdx.x] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+}
+
+__global__ __launch_bounds__(256) void rs_scan_rows(uint32_t *__restrict__ table, uint32_t ntiles,
+                                                     uint32_t *__restrict__ totals) {
+	__shared__ uint32_t part[4];
+	uint32_t *row = table + (size_t)blockIdx.x * ntiles;
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < ntiles; base += 1024) {
+		// 4 consecutive entries per thread
+		uint32_t i0 = base + threadIdx.x * 4;
+		uint32_t v[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) v[j] = (i0 + j < ntiles) ? row[i0 + j] : 0u;
+		uint32_t s = v[0] + v[1] + v[2] + v[3], tot;
+		uint32_t ex = block_excl_scan_256(s, part, &tot) + carry;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if (i0 + j < ntiles) row[i0 + j] = ex;
+			ex += v[j];
+		}
+		carry += tot;
+	}
+	if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void rs_scatter(const uint32_t *__restrict__ keys_in,
+                                                       const uint32_t *__restrict__ vals_in,
+                                                       uint32_t *__restrict__ keys_out,
+                                                       uint32_t *__restrict__ vals_out, uint32_t n,
+                                                       int shift, const uint32_t *__restrict__ table,
+                                                       const uint32_t *__restrict__ totals,
+                                                       uint32_t ntiles) {
+	__shared__ uint32_t s_keys[RS_TILE];
+	__shared__ uint32_t s_vals[RS_TILE];
+	__shared__ uint32_t s_whist[4][256];
+	__shared__ uint32_t s_goff[256];
+	__shared__ uint32_t s_part[4];
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) s_whist[i][tid] = 0;
+	__syncthreads();
+
+	// wave-striped tile order: (wave, item, lane) -- each load is 64 consecutive keys
+	const uint32_t tile_base = blockIdx.x * RS_TILE;
+	const uint32_t base = tile_base + w * (64 * RS_ITEMS) + lane;
+	uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; ++i) {
+		uint32_t idx = base + i * 64;
+		bool ok = idx < n;
+		key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu; // padding sorts last inside the tile
+		val[i] = ok ? (vals_in ? vals_in[idx] : idx) : 0u;
+	}
+	const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; ++i) {
+		const uint32_t d = (key[i] >> shift) & 255u;
+		uint64_t peers = ~0ull; // lanes holding the same digit (match-any by 8 ballots)
+#pragma unroll
+		for (int b = 0; b < 8; ++b) {
+			const bool bit = (d >> b) & 1u;
+			const uint64_t m = __ballot(bit);
+			peers &= bit ? m : ~m;
+		}
+		const uint32_t cnt = __popcll(peers);
+		const int leader = 63 - __clzll((long long)peers);
+		uint32_t old = 0;
+		if (lane == leader) old = atomicAdd(&s_whist[w][d], cnt);
+		old = __shfl(old, leader, 64);
+		rank[i] = old + __popcll(peers & lt_mask);
+	}
+	__syncthreads();
+
+	{ // digit starts inside the tile, per-wave bases, global offsets
+		const uint32_t c0 = s_whist[0][tid], c1 = s_whist[1][tid], c2 = s_whist[2][tid], c3 = s_whist[3][tid];
+		const uint32_t dstart = block_excl_scan_256(c0 + c1 + c2 + c3, s_part, nullptr);
+		const uint32_t gstart = block_excl_scan_256(totals[tid], s_part, nullptr);
+		s_whist[0][tid] = dstart;
+		s_whist[1][tid] = dstart + c0;
+		s_whist[2][tid] = dstart + c0 + c1;
+		s_whist[3][tid] = dstart + c0 + c1 + c2;
+		s_goff[tid] = gstart + table[(uint32_t)tid * ntiles + blockIdx.x] - dstart;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; ++i) {
+		const uint32_t d = (key[i] >> shift) & 255u;
+		const uint32_t pos = s_whist[w][d] + rank[i];
+		s_keys[pos] = key[i];
+		s_vals[pos] = val[i];
+	}
+	__syncthreads();
+	const uint32_t tile_count = (n - tile_base) < (uint32_t)RS_TILE ? (n - tile_base) : (uint32_t)RS_TILE;
+#pragma unroll
+	for (int i = 0; i < RS_ITEMS; ++i) {
+		const uint32_t p = i * RS_BLOCK + tid;
+		if (p < tile_count) {
+			const uint32_t k = s_keys[p];
+			const uint32_t o = s_goff[(k >> shift) & 255u] + p;
+			keys_out[o] = k;
+			vals_out[o] = s_vals[p];
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_iota_copy(const uint32_t *__restrict__ keys_in,
+                                                    const uint32_t *__restrict__ vals_in,
+                                                    uint32_t *__restrict__ keys_out,
+                                                    uint32_t *__restrict__ vals_out, uint32_t n) {
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	keys_out[i] = keys_in[i];
+	vals_out[i] = vals_in ? vals_in[i] : i;
+}
+
+int32_t sort_pairs_dev(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in,
+                       uint64_t n64, int bits, uint32_t *d_keys_out, uint32_t *d_vals_out) {
+	if (n64 == 0) return TREEE_OK;
+	if (n64 >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "sort: n=%llu exceeds 2^31-1 per shard", (unsigned long long)n64);
+	const uint32_t n = (uint32_t)n64;
+	const int passes = bits <= 0 ? 0 : (bits + 7) / 8;
+	if (passes == 0) {
+		hipLaunchKernelGGL(k_iota_copy, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_keys_in, d_vals_in, d_keys_out, d_vals_out, n);
+		TREEE_LAUNCH_CHECK();
+		return TREEE_OK;
+	}
+	const uint32_t ntiles = div_up(n, RS_TILE);
+	uint32_t *d_table = nullptr, *d_totals = nullptr, *d_ktmp = nullptr, *d_vtmp = nullptr;
+	TREEE_TRY(ctx->alloc_t((size_t)256 * ntiles, &d_table));
+	TREEE_TRY(ctx->alloc_t(256, &d_totals));
+	TREEE_TRY(ctx->alloc_t(n, &d_ktmp));
+	TREEE_TRY(ctx->alloc_t(n, &d_vtmp));
+	// ping-pong so that the last pass lands in the caller's output buffers
+	const uint32_t *kin = d_keys_in, *vin = d_vals_in;
+	for (int p = 0; p < passes; ++p) {
+		const bool to_out = ((passes - 1 - p) % 2) == 0;
+		uint32_t *kout = to_out ? d_keys_out : d_ktmp;
+		uint32_t *vout = to_out ? d_vals_out : d_vtmp;
+		const int shift = 8 * p;
+		hipLaunchKernelGGL(rs_hist, dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, kin, n, shift, d_table, ntiles);
+		hipLaunchKernelGGL(rs_scan_rows, dim3(256), dim3(256), 0, ctx->stream, d_table, ntiles, d_totals);
+		hipLaunchKernelGGL(rs_scatter, dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, kin, vin, kout, vout, n, shift, d_table, d_totals, ntiles);
+		TREEE_LAUNCH_CHECK();
+		kin = kout;
+		vin = vout;
+	}
+	return TREEE_OK;
+}
+
+// ---- exclusive scan (u32) --------------------------------------------------------------------
+constexpr int SC_ITEMS = 4;
+constexpr int SC_TILE = 256 * SC_ITEMS;
+
+__global__ __launch_bounds__(256) void sc_reduce(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ sums) {
+	__shared__ uint32_t part[4];
+	uint32_t i0 = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS, s = 0;
+#pragma unroll
+	for (int j = 0; j < SC_ITEMS; ++j) s += (i0 + j < n) ? in[i0 + j] : 0u;
+	uint32_t tot;
+	block_excl_scan_256(s, part, &tot);
+	if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void sc_scan_sums(uint32_t *__restrict__ sums, uint32_t nb, uint32_t *__restrict__ total_out) {
+	__shared__ uint32_t part[4];
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < nb; base += 256) {
+		uint32_t i = base + threadIdx.x, v = i < nb ? sums[i] : 0u, tot;
+		uint32_t ex = block_excl_scan_256(v, part, &tot);
+		if (i < nb) sums[i] = carry + ex;
+		carry += tot;
+	}
+	if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void sc_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ sums) {
+	__shared__ uint32_t part[4];
+	uint32_t i0 = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS, v[SC_ITEMS], s = 0;
+#pragma unroll
+	for (int j = 0; j < SC_ITEMS; ++j) {
+		v[j] = (i0 + j < n) ? in[i0 + j] : 0u;
+		s += v[j];
+	}
+	uint32_t ex = block_excl_scan_256(s, part, nullptr) + sums[blockIdx.x];
+#pragma unroll
+	for (int j = 0; j < SC_ITEMS; ++j) {
+		if (i0 + j < n) out[i0 + j] = ex;
+		ex += v[j];
+	}
+}
+
+int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_total) {
+	if (n == 0) {
+		if (d_total) TREEE_HIP(hipMemsetAsync(d_total, 0, 4, ctx->stream));
+		return TREEE_OK;
+	}
+	uint32_t nb = div_up(n, SC_TILE);
+	uint32_t *d_sums = nullptr;
+	TREEE_TRY(ctx->alloc_t(nb, &d_sums));
+	hipLaunchKernelGGL(sc_reduce, dim3(nb), dim3(256), 0, ctx->stream, d_in, (uint32_t)n, d_sums);
+	hipLaunchKernelGGL(sc_scan_sums, dim3(1), dim3(256), 0, ctx->stream, d_sums, nb, d_total);
+	hipLaunchKernelGGL(sc_apply, dim3(nb), dim3(256), 0, ctx->stream, d_in, d_out, (uint32_t)n, d_sums);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+// ---- gather into sorted order ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_sorted(const float *__restrict__ xyz, const uint32_t *__restrict__ perm,
+                                                        uint32_t n, float4 *__restrict__ out) {
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	uint32_t o = perm[i];
+	out[i] = make_float4(xyz[3ull * o + 0], xyz[3ull * o + 1], xyz[3ull * o + 2], __uint_as_float(o));
+}
+
+int32_t gather_sorted_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_perm, uint64_t n, float4 *d_sorted) {
+	if (n == 0) return TREEE_OK;
+	hipLaunchKernelGGL(k_gather_sorted, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_xyz, d_perm, (uint32_t)n, d_sorted);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+void SortedCloud::release() {
+	if (d_keys) (void)hipFree(d_keys);
+	if (d_perm) (void)hipFree(d_perm);
+	if (d_sorted) (void)hipFree(d_sorted);
+	d_keys = d_perm = nullptr;
+	d_sorted = nullptr;
+}
+
+int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc) {
+	sc->n = n;
+	if (n >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per shard", (unsigned long long)n);
+	if (corner && size > 0.0f) {
+		for (int a = 0; a < 3; ++a) sc->corner[a] = corner[a];
+		sc->size = size;
+	} else {
+		TREEE_TRY(bbox_dev(ctx, d_xyz, n, sc->corner, &sc->size));
+	}
+	size_t cnt = n ? n : 1;
+	TREEE_HIP(hipMalloc((void **)&sc->d_keys, cnt * 4));
+	TREEE_HIP(hipMalloc((void **)&sc->d_perm, cnt * 4));
+	TREEE_HIP(hipMalloc((void **)&sc->d_sorted, cnt * 16));
+	uint32_t *d_keys_raw = nullptr;
+	TREEE_TRY(ctx->alloc_t(cnt, &d_keys_raw));
+	TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
+	TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, sc->d_keys, sc->d_perm));
+	TREEE_TRY(gather_sorted_dev(ctx, d_xyz, sc->d_perm, n, sc->d_sorted));
+	return TREEE_OK;
+}
+
+} // namespace treee

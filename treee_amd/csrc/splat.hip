@@ -1,0 +1,261 @@
+// splat.hip -- compute point-splat into a depth + id buffer, replacing the instanced-triangle
+// pipeline of the `render` crate:
+//   vertex    render/src/point_cloud.wgsl:37-59   (value-range cull, view*p, billboard, proj)
+//   fragment  render/src/point_cloud.wgsl:72-80   (unit-disc discard)
+//   state     render/src/point_cloud.rs:76-82     (Depth32Float, Less, write), window.rs:153-159
+//             (clear 1.0), wgpu clip volume 0 <= z <= w
+//   eye dome  render/src/eye_dome.wgsl:37-67
+// Coverage rule, float op order and tie rule are exactly those of oracle/splat_oracle.cpp.
+//
+// MI355X design: one lane per point; the depth test is a 64-bit atomicMin on
+// (depth_bits << 32 | point index) -- depth in [0,1) so IEEE bits order like unsigned ints,
+// and the low word makes "first drawn wins" on equal depth.  A plain (possibly stale) load
+// of the pixel filters out occluded fragments first: values only decrease, so a stale value
+// is conservative.  Splats whose pixel box exceeds 256 pixels are deferred to a
+// workgroup-per-splat kernel so one lane never serialises a huge disc.
+#include "common.h"
+
+using namespace treee;
+
+namespace {
+
+constexpr uint64_t PACKED_CLEAR = (0x3F800000ull << 32) | 0xFFFFFFFFull; // depth 1.0, no point
+constexpr int LARGE_AREA = 256;
+
+struct SplatParams {
+	float view[16], proj[16];
+	float scale;
+	uint32_t vmin, vmax, w, h, index_base;
+};
+
+struct Foot { // screen footprint of one splat
+	float depth, sx, sy, rx, ry;
+	int x0, x1, y0, y1;
+};
+
+__device__ __forceinline__ int clampi(float f, int lo, int hi) {
+	if (!(f >= (float)lo)) return lo;
+	if (f >= (float)hi) return hi;
+	return (int)f;
+}
+
+__device__ __forceinline__ bool footprint(const SplatParams &P, float x, float y, float z, uint32_t val, Foot &f) {
+	if (val < P.vmin || P.vmax < val) return false; // point_cloud.wgsl:44-49
+	float pos[4], clip[4];
+#pragma unroll
+	for (int r = 0; r < 4; ++r) pos[r] = ((P.view[0 + r] * x + P.view[4 + r] * y) + P.view[8 + r] * z) + P.view[12 + r];
+#pragma unroll
+	for (int r = 0; r < 4; ++r)
+		clip[r] = ((P.proj[0 + r] * pos[0] + P.proj[4 + r] * pos[1]) + P.proj[8 + r] * pos[2]) + P.proj[12 + r] * pos[3];
+	const float w = clip[3];
+	if (!(w > 0.0f)) return false;
+	f.depth = clip[2] / w;
+	if (!(f.depth >= 0.0f && f.depth < 1.0f)) return false;
+	const float fw = (float)P.w, fh = (float)P.h;
+	const float ndc_x = clip[0] / w, ndc_y = clip[1] / w;
+	f.sx = (ndc_x * 0.5f + 0.5f) * fw;
+	f.sy = (0.5f - ndc_y * 0.5f) * fh;
+	f.rx = fabsf(P.proj[0] * P.scale / w) * (0.5f * fw);
+	f.ry = fabsf(P.proj[5] * P.scale / w) * (0.5f * fh);
+	if (!(f.rx > 0.0f && f.ry > 0.0f)) return false;
+	f.x0 = clampi(floorf(f.sx - f.rx - 0.5f) - 1.0f, 0, (int)P.w);
+	f.x1 = clampi(ceilf(f.sx + f.rx - 0.5f) + 2.0f, 0, (int)P.w);
+	f.y0 = clampi(floorf(f.sy - f.ry - 0.5f) - 1.0f, 0, (int)P.h);
+	f.y1 = clampi(ceilf(f.sy + f.ry - 0.5f) + 2.0f, 0, (int)P.h);
+	return f.x0 < f.x1 && f.y0 < f.y1;
+}
+
+__device__ __forceinline__ void plot(unsigned long long *packed, uint32_t w, const Foot &f, int px, int py, unsigned long long mine) {
+	const float v = (((float)py + 0.5f) - f.sy) / f.ry;
+	const float u = (((float)px + 0.5f) - f.sx) / f.rx;
+	if (!(u * u + v * v < 1.0f)) return; // point_cloud.wgsl:74-76
+	unsigned long long *p = packed + (size_t)py * w + px;
+	if (mine < *p) atomicMin(p, mine); // stale read is conservative: values only decrease
+}
+
+__global__ __launch_bounds__(256) void k_splat_clear(unsigned long long *packed, uint32_t count) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < count) packed[i] = PACKED_CLEAR;
+}
+
+__global__ __launch_bounds__(256) void k_splat_points(const float *__restrict__ xyz, const uint32_t *__restrict__ value, uint32_t n,
+                                                       SplatParams P, unsigned long long *packed,
+                                                       uint32_t *__restrict__ large_count, uint32_t *__restrict__ large_list) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	Foot f;
+	if (!footprint(P, xyz[3ull * i + 0], xyz[3ull * i + 1], xyz[3ull * i + 2], value[i], f)) return;
+	if ((f.x1 - f.x0) * (f.y1 - f.y0) > LARGE_AREA) {
+		large_list[atomicAdd(large_count, 1u)] = i;
+		return;
+	}
+	const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + i);
+	for (int py = f.y0; py < f.y1; ++py)
+		for (int px = f.x0; px < f.x1; ++px) plot(packed, P.w, f, px, py, mine);
+}
+
+__global__ __launch_bounds__(256) void k_splat_large(const float *__restrict__ xyz, const uint32_t *__restrict__ value,
+                                                      SplatParams P, unsigned long long *packed,
+                                                      const uint32_t *__restrict__ large_count, const uint32_t *__restrict__ large_list) {
+	const uint32_t total = *large_count;
+	for (uint32_t s = blockIdx.x; s < total; s += gridDim.x) {
+		const uint32_t i = large_list[s];
+		Foot f;
+		if (!footprint(P, xyz[3ull * i + 0], xyz[3ull * i + 1], xyz[3ull * i + 2], value[i], f)) continue;
+		const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + i);
+		const int bw = f.x1 - f.x0;
+		const int area = bw * (f.y1 - f.y0);
+		for (int t = threadIdx.x; t < area; t += 256) plot(packed, P.w, f, f.x0 + t % bw, f.y0 + t / bw, mine);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_splat_resolve(const unsigned long long *__restrict__ packed, const uint32_t *__restrict__ value,
+                                                        uint32_t n_values, uint32_t count, float *__restrict__ depth, uint32_t *__restrict__ id) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= count) return;
+	const unsigned long long v = packed[i];
+	const uint32_t idx = (uint32_t)v;
+	if (depth) depth[i] = __uint_as_float((uint32_t)(v >> 32));
+	if (id) id[i] = (idx == 0xFFFFFFFFu || idx >= n_values) ? 0u : value[idx];
+}
+
+// render/src/eye_dome.wgsl:37-67
+__device__ __forceinline__ float ed_depth(const float *__restrict__ depth, int w, int h, int x, int y) {
+	x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+	y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+	const float near = 0.1f, far = 10000.0f;
+	const float d = depth[(size_t)y * w + x];
+	if (d >= 1.0f) return 1.0f;
+	return (2.0f * near) / (far + near - d * (far - near));
+}
+
+__global__ __launch_bounds__(256) void k_eye_dome(const float *__restrict__ depth, uint32_t w, uint32_t h, float strength, float *__restrict__ alpha) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= w * h) return;
+	const int x = i % w, y = i / w;
+	const float d = ed_depth(depth, w, h, x, y);
+	float a = 0.0f;
+	if (d != 1.0f) {
+		float m = d;
+		m = fmaxf(m, ed_depth(depth, w, h, x - 1, y));
+		m = fmaxf(m, ed_depth(depth, w, h, x + 1, y));
+		m = fmaxf(m, ed_depth(depth, w, h, x, y - 1));
+		m = fmaxf(m, ed_depth(depth, w, h, x, y + 1));
+		m = fminf(m, d + strength);
+		a = (m - d) / strength;
+	}
+	alpha[i] = a;
+}
+
+int32_t check_proj(const float proj[16]) {
+	// x row must not read y, y row must not read x, z/w rows must not read x or y: then a
+	// view-plane disc is an axis-aligned screen ellipse with constant depth
+	if (proj[4] != 0.0f || proj[1] != 0.0f || proj[2] != 0.0f || proj[6] != 0.0f || proj[3] != 0.0f || proj[7] != 0.0f)
+		return set_err(TREEE_ERR_UNSUPPORTED, "projection matrix mixes x/y into other rows; only perspective/orthographic forms are supported");
+	return TREEE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_value, uint64_t n, const float view[16],
+                        const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h,
+                        uint64_t *d_packed, int32_t accumulate, uint32_t index_base, float *d_depth, uint32_t *d_id) {
+	if (!ctx || !view || !proj || (n && (!d_xyz || !d_value))) return set_err(TREEE_ERR_INVALID, "treee_splat_dev: null argument");
+	if (w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 31)) return set_err(TREEE_ERR_INVALID, "bad framebuffer size %ux%u", w, h);
+	if (n >= 0xFFFFFFFFull - index_base) return set_err(TREEE_ERR_UNSUPPORTED, "point index does not fit in 32 bits");
+	if (index_base != 0 && d_id)
+		return set_err(TREEE_ERR_INVALID, "d_id_out needs index_base == 0; resolve multi-chunk draws with treee_splat_resolve_dev");
+	TREEE_TRY(check_proj(proj));
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	const uint32_t px = w * h;
+	unsigned long long *packed = (unsigned long long *)d_packed;
+	if (!packed) {
+		TREEE_TRY(ctx->alloc_t(px, &packed));
+		accumulate = 0;
+	}
+	SplatParams P;
+	memcpy(P.view, view, 64);
+	memcpy(P.proj, proj, 64);
+	P.scale = scale;
+	P.vmin = vmin;
+	P.vmax = vmax;
+	P.w = w;
+	P.h = h;
+	P.index_base = index_base;
+	hipStream_t st = ctx->stream;
+	if (!accumulate) hipLaunchKernelGGL(k_splat_clear, dim3(div_up(px, 256)), dim3(256), 0, st, packed, px);
+	if (n) {
+		uint32_t *d_lc = nullptr, *d_ll = nullptr;
+		TREEE_TRY(ctx->alloc_t(1, &d_lc));
+		TREEE_TRY(ctx->alloc_t(n, &d_ll));
+		TREEE_HIP(hipMemsetAsync(d_lc, 0, 4, st));
+		hipLaunchKernelGGL(k_splat_points, dim3(div_up(n, 256)), dim3(256), 0, st, d_xyz, d_value, (uint32_t)n, P, packed, d_lc, d_ll);
+		hipLaunchKernelGGL(k_splat_large, dim3(ctx->num_cus * 4), dim3(256), 0, st, d_xyz, d_value, P, packed, d_lc, d_ll);
+	}
+	if (d_depth || d_id)
+		hipLaunchKernelGGL(k_splat_resolve, dim3(div_up(px, 256)), dim3(256), 0, st, packed, d_value, (uint32_t)n, px, d_depth, d_id);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+int32_t treee_splat_resolve_dev(treee_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_value, uint64_t n_values, uint32_t w,
+                                uint32_t h, float *d_depth, uint32_t *d_id) {
+	if (!ctx || !d_packed) return set_err(TREEE_ERR_INVALID, "treee_splat_resolve_dev: null argument");
+	if (d_id && n_values && !d_value) return set_err(TREEE_ERR_INVALID, "treee_splat_resolve_dev: value is null");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	const uint32_t px = w * h;
+	hipLaunchKernelGGL(k_splat_resolve, dim3(div_up(px, 256)), dim3(256), 0, ctx->stream, (const unsigned long long *)d_packed, d_value,
+	                   (uint32_t)n_values, px, d_depth, d_id);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+int32_t treee_splat(const float *xyz, const uint32_t *value, uint64_t n, const float view[16], const float proj[16], float scale,
+                    uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h, float *depth_out, uint32_t *id_out) {
+	if (!view || !proj || (n && (!xyz || !value))) return set_err(TREEE_ERR_INVALID, "treee_splat: null argument");
+	treee_ctx *ctx = nullptr;
+	TREEE_TRY(default_ctx(&ctx));
+	TREEE_HIP(hipSetDevice(ctx->device));
+	const uint64_t px = (uint64_t)w * h;
+	DevBuf<float> d_xyz, d_depth;
+	DevBuf<uint32_t> d_val, d_id;
+	TREEE_TRY(d_xyz.alloc(n * 3));
+	TREEE_TRY(d_val.alloc(n));
+	TREEE_TRY(d_depth.alloc(px));
+	TREEE_TRY(d_id.alloc(px));
+	if (n) {
+		TREEE_HIP(hipMemcpyAsync(d_xyz.p, xyz, n * 12, hipMemcpyHostToDevice, ctx->stream));
+		TREEE_HIP(hipMemcpyAsync(d_val.p, value, n * 4, hipMemcpyHostToDevice, ctx->stream));
+	}
+	TREEE_TRY(treee_splat_dev(ctx, d_xyz.p, d_val.p, n, view, proj, scale, vmin, vmax, w, h, nullptr, 0, 0, d_depth.p, d_id.p));
+	if (depth_out) TREEE_HIP(hipMemcpyAsync(depth_out, d_depth.p, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+	if (id_out) TREEE_HIP(hipMemcpyAsync(id_out, d_id.p, px * 4, hipMemcpyDeviceToHost, ctx->stream));
+	TREEE_HIP(hipStreamSynchronize(ctx->stream));
+	return TREEE_OK;
+}
+
+int32_t treee_perspective(float aspect, float fovy, float znear, float zfar, float out[16]) {
+	if (!out) return set_err(TREEE_ERR_INVALID, "treee_perspective: out is null");
+	// nalgebra 0.33 Perspective3::new: identity, m33=0, m32=-1, set_fovy, set_aspect, set_znear_and_zfar
+	memset(out, 0, 64);
+	const float m11 = 1.0f / tanf(fovy / 2.0f);
+	out[0] = m11 / aspect;
+	out[5] = m11;
+	out[10] = (zfar + znear) / (znear - zfar);
+	out[14] = zfar * znear * 2.0f / (znear - zfar);
+	out[11] = -1.0f;
+	return TREEE_OK;
+}
+
+int32_t treee_eye_dome_dev(treee_ctx *ctx, const float *d_depth, uint32_t w, uint32_t h, float strength, float *d_alpha) {
+	if (!ctx || !d_depth || !d_alpha) return set_err(TREEE_ERR_INVALID, "treee_eye_dome_dev: null argument");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	hipLaunchKernelGGL(k_eye_dome, dim3(div_up((uint64_t)w * h, 256)), dim3(256), 0, ctx->stream, d_depth, w, h, strength, d_alpha);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+} // extern "C"

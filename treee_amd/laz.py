@@ -1,0 +1,137 @@
+"""Mirror of the ingest seam: treee/src/laz.rs (`Laz::new`, `Laz::read`, `Chunk::read`) for
+uncompressed LAS, and the y-slice binning of treee/src/loading.rs:91-115.
+
+LAZ arithmetic decompression is the third-party crate `laz` 0.9.2 and is not part of this
+path: a .laz source raises NotImplementedError."""
+import struct
+
+import numpy as np
+
+from . import _lib
+from .context import default_context, dev_f32, host_f32, is_device, ptr
+
+DEFAULT_CHUNK_SIZE = 50_000  # laz.rs:98
+HEADER_BYTES = 375  # the packed struct read regardless of version (laz.rs:228-277)
+
+
+class CorruptFile(Exception):  # Error::CorruptFile
+    pass
+
+
+class Header:
+    """laz.rs:228-287 (fixed 375-byte LAS-1.4-shaped layout)."""
+
+    def __init__(self, data):
+        if len(data) < HEADER_BYTES:
+            raise CorruptFile("short header")
+        b = bytes(data[:HEADER_BYTES])
+        if b[0:4] != b"LASF":
+            raise CorruptFile("signature")
+        self.version_major, self.version_minor = b[24], b[25]
+        self.header_size, self.offset_to_point_data, self.number_of_variable_length_records = struct.unpack_from("<HII", b, 94)
+        self.point_data_record_format = b[104]
+        (self.point_data_record_length,) = struct.unpack_from("<H", b, 105)
+        (legacy,) = struct.unpack_from("<I", b, 107)
+        self.scale = np.array(struct.unpack_from("<3d", b, 131))
+        self.offset = np.array(struct.unpack_from("<3d", b, 155))
+        max_x, min_x, max_y, min_y, max_z, min_z = struct.unpack_from("<6d", b, 179)
+        (self.number_of_point_records,) = struct.unpack_from("<Q", b, 247)
+        if legacy != 0:  # laz.rs:279-281
+            self.number_of_point_records = legacy
+        self.min = np.array([min_x, min_z, -max_y])  # laz.rs:72
+        self.max = np.array([max_x, max_z, -min_y])  # laz.rs:73
+
+
+class Chunk:
+    """laz.rs:184-213: raw record bytes + the decode parameters."""
+
+    def __init__(self, data, point_length, offset, scale, center):
+        self.slice, self.point_length = data, point_length
+        self.offset, self.scale, self.center = (np.ascontiguousarray(a, dtype=np.float64) for a in (offset, scale, center))
+
+    def read(self, ctx=None):
+        """Chunk::read -> Vec<Point3<f32>> (numpy in, numpy out; torch uint8 CUDA in, torch out)."""
+        if is_device(self.slice):
+            import torch
+
+            n = self.slice.numel() // self.point_length
+            c = ctx or default_context(self.slice.device)
+            out = torch.empty((n, 3), dtype=torch.float32, device=self.slice.device)
+            _lib.check(
+                _lib.lib().treee_decode_las_records_dev(
+                    c.handle, ptr(self.slice), n, self.point_length, ptr(self.scale), ptr(self.offset), ptr(self.center), ptr(out)
+                )
+            )
+            return out
+        rec = np.frombuffer(self.slice, dtype=np.uint8) if not isinstance(self.slice, np.ndarray) else self.slice
+        rec = np.ascontiguousarray(rec)
+        n = len(rec) // self.point_length
+        out = np.zeros((n, 3), np.float32)
+        _lib.check(
+            _lib.lib().treee_decode_las_records(ptr(rec), n, self.point_length, ptr(self.scale), ptr(self.offset), ptr(self.center), ptr(out))
+        )
+        return out
+
+
+class Laz:
+    """Laz::new(source, center) over an in-memory .las image (bytes)."""
+
+    def __init__(self, data, center=None):
+        self.data = bytes(data)
+        h = self.header = Header(self.data)
+        self.point_length = h.point_data_record_length
+        self.scale, self.offset = h.scale, h.offset
+        self.center = (h.min + h.max) * 0.5 if center is None else np.asarray(center, dtype=np.float64)  # na::center
+        if h.point_data_record_format & 0x80:
+            raise NotImplementedError("LAZ-compressed point data (crate `laz` 0.9.2) is outside this path")
+        total = h.number_of_point_records
+        self.chunks = []  # laz.rs:96-107
+        start = h.offset_to_point_data
+        for _ in range(total // DEFAULT_CHUNK_SIZE):
+            self.chunks.append((start, DEFAULT_CHUNK_SIZE))
+            start += DEFAULT_CHUNK_SIZE * self.point_length
+        if total % DEFAULT_CHUNK_SIZE:
+            self.chunks.append((start, total % DEFAULT_CHUNK_SIZE))
+        self.min = (h.min - self.center).astype(np.float32)
+        self.max = (h.max - self.center).astype(np.float32)
+        self.world_offset = self.center
+
+    def total(self):
+        return len(self.chunks)
+
+    def read(self, cb):
+        """Laz::read(cb): hands one Chunk per (start, length) to the callback."""
+        for s, l in self.chunks:
+            cb(Chunk(self.data[s : s + l * self.point_length], self.point_length, self.offset, self.scale, self.center))
+
+
+def slice_keys(points, ctx=None):
+    """loading.rs:99: idx = p.y.floor() as isize."""
+    if is_device(points):
+        import torch
+
+        p = dev_f32(points, 3)
+        c = ctx or default_context(p.device)
+        out = torch.empty((p.shape[0],), dtype=torch.int64, device=p.device)
+        _lib.check(_lib.lib().treee_slice_keys_dev(c.handle, ptr(p), p.shape[0], ptr(out)))
+        return out
+    p = host_f32(points, 3)
+    out = np.zeros(len(p), np.int64)
+    _lib.check(_lib.lib().treee_slice_keys(ptr(p), len(p), ptr(out)))
+    return out
+
+
+def slice_bin(points):
+    """Shared.slices (loading.rs:28,97-101) densified like segmenting.rs:121-133.
+    Returns (min_key, order[n] u32, offsets[layers+1] u64)."""
+    import ctypes as C
+
+    p = host_f32(points, 3)
+    n = len(p)
+    mn, layers = C.c_int64(0), C.c_uint64(0)
+    _lib.check(_lib.lib().treee_slice_bin(ptr(p), n, C.byref(mn), C.byref(layers), None, None, 0))
+    order = np.zeros(n, np.uint32)
+    offsets = np.zeros(layers.value + 1 if n else 0, np.uint64)
+    if n:
+        _lib.check(_lib.lib().treee_slice_bin(ptr(p), n, C.byref(mn), C.byref(layers), ptr(order), ptr(offsets), len(offsets)))
+    return int(mn.value), order, offsets
