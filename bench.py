@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of BASELINE.json on N GPUs of one node.
+
+A "step" is one pass of the whole path over one synthetic forest cloud that is already
+resident in HBM: [N>1: ghost-point all-gather] -> Morton keys + radix sort + octree/LOD ->
+kNN structure + k=31 neighbours + curvature (treee/src/calculations.rs:328-373) ->
+map_to_u32 -> splat into a 1920x1080 depth+id buffer [N>1: MIN all-reduce of the packed
+frame].  Weak scaling: every rank owns one 15 M-point 200 m x 200 m tile.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      for the dominant kernel (the kNN/curvature kernel), measured live with HIP
+                events on the stream the kernel runs on
+  cpu_baseline  the CPU oracle (a port of the reference algorithms) timed on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+K = 31  # treee/src/calculations.rs:278
+F32_MAX = float(np.finfo(np.float32).max)  # calculations.rs:279
+W, H = 1920, 1080
+PLOT = 200.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# algorithmic bytes per point (SURVEY.md section 8 D / BASELINE.md section 3)
+BYTES = {"keys_sort_octree": 20 + 68 + 40, "knn_curve": 340, "splat": 16}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=15_000_000, help="points per GPU")
+    ap.add_argument("--halo", type=float, default=2.0)
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class Stage:
+    """HIP-event timer on torch's current stream (the stream every treee kernel runs on)."""
+
+    def __init__(self):
+        self.t = {}
+
+    def run(self, name, fn, record):
+        if not record:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.t.setdefault(name, []).append((a, b))
+        return out
+
+    def mean_ms(self):
+        torch.cuda.synchronize()
+        return {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in self.t.items()}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import treee_amd as T
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    T.lib()
+    ctx = T.default_context(dev)
+    n = args.points
+    origin = D.tile_origin(rank, world, PLOT)
+    bounds = D.tile_bounds(rank, world, PLOT)
+    pts, seg = synth.forest_cloud_torch(n, dev, plot=PLOT, seed=synth.SEED_FOREST + rank, origin=origin)
+    cam = T.Camera3D(W / H)
+    proj = cam.projection()
+    span = PLOT * max(D.tile_grid(world))
+    view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 100.0 + 0.9 * span))
+    env = T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+    packed = torch.empty((H, W), dtype=torch.int64, device=dev)
+    depth = torch.empty((H, W), dtype=torch.float32, device=dev)
+    ids = torch.empty((H, W), dtype=torch.int32, device=dev)
+    curve = torch.empty((n + n // 8,), dtype=torch.float32, device=dev)
+    ctx.reserve(int(n * 1.15) * 48 + (64 << 20))
+    stages = Stage()
+    halo = args.halo
+    state = {}
+
+    def step(record):
+        nonlocal halo
+        if world > 1:
+            ghosts = stages.run("ghost_allgather", lambda: D.exchange_ghosts(pts, bounds, halo, rank, world), record)
+            cloud = torch.cat([pts, ghosts]) if ghosts.shape[0] else pts
+        else:
+            cloud = pts
+        m = cloud.shape[0]
+        oc = stages.run("keys_sort_octree", lambda: T.Octree(pts, ctx=ctx), record)
+        if m == n:  # no ghosts: the octree's Morton-sorted cloud feeds the kNN structure too
+            tree = stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
+        else:
+            tree = stages.run("knn_build", lambda: T.KDTree.new(cloud, ctx), record)
+        cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
+        stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv), record)
+        val = stages.run("map_to_u32", lambda: T.map_to_u32_dev(cv[:n], ctx), record)
+
+        def splat():
+            T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), T.context.ptr(val), n, T.context.ptr(view), T.context.ptr(proj),
+                                                 env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, rank * n, None, None))
+            if world > 1:
+                D.reduce_packed_min(packed)
+            T._lib.check(T.lib().treee_splat_resolve_dev(ctx.handle, T.context.ptr(packed), T.context.ptr(val), n, W, H, T.context.ptr(depth),
+                                                         T.context.ptr(ids) if world == 1 else None))
+
+        stages.run("splat", splat, record)
+        state["oc"], state["tree"], state["curve"], state["cloud_n"] = oc, tree, cv, m
+        return oc, tree
+
+    def free_state():
+        for k in ("oc", "tree"):
+            if state.get(k) is not None:
+                state[k].close()
+                state[k] = None
+
+    for _ in range(args.warmup):
+        step(False)
+        torch.cuda.synchronize()
+        free_state()
+
+    # multi-GPU exactness of the unbounded-radius kNN: verify the halo once, outside the timing
+    if world > 1:
+        step(False)
+        tree = state["tree"]
+        d, _, _ = tree.self_neighbors_dev(K, F32_MAX, ctx, want_index=False)
+        ok = D.halo_is_sufficient(pts, d[:n, K - 1], bounds, halo, rank, world)
+        del d
+        free_state()
+        if not ok:
+            halo *= 2.0
+            if rank == 0:
+                print(f"# halo widened to {halo} m", file=sys.stderr)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        # handles of the previous step are released outside the kernels' critical path:
+        # hipFree synchronises, so free only after the step has been fully enqueued
+        torch.cuda.synchronize()
+        free_state()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = stages.mean_ms()
+
+    if rank == 0:
+        total_points = n * world * args.steps
+        value = total_points / elapsed / 1e6
+        knn_ms = ms["knn_curve"]
+        m_knn = state["cloud_n"]
+        achieved = BYTES["knn_curve"] * m_knn / (knn_ms * 1e-3) / 1e9
+        stage_roof = {}
+        for name, b in BYTES.items():
+            pts_in = m_knn if name == "knn_curve" else n
+            extra = 24 * W * H if name == "splat" else 0
+            gbs = (b * pts_in + extra) / (ms[name] * 1e-3) / 1e9
+            stage_roof[name] = {"ms": round(ms[name], 3), "achieved_GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        for name in ms:
+            if name not in stage_roof:
+                stage_roof[name] = {"ms": round(ms[name], 3)}
+        out = {
+            "metric": "Mpoints/s octree+kNN+splat (15M-point synthetic forest per GPU)",
+            "value": round(value, 3),
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"forest {n} pts/GPU on {PLOT:.0f}m tile: morton radix sort + octree/LOD + kNN k=31 r=f32::MAX + curvature + splat {W}x{H}",
+                "points_per_gpu": n,
+                "k": K,
+                "framebuffer": [W, H],
+                "parallelism": f"spatial x/z tiles {D.tile_grid(world)[0]}x{D.tile_grid(world)[1]}, ghost all-gather halo {halo} m",
+            },
+            "roofline": {
+                "kernel": "k_knn (kNN k=31 + covariance/eigen -> curve)",
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "algorithmic_bytes_per_point": BYTES["knn_curve"],
+                "points_per_launch": m_knn,
+                "kernel_ms": round(knn_ms, 3),
+            },
+            "stages": stage_roof,
+            "end_to_end_GBps": round((sum(BYTES.values()) * n + 24 * W * H) / (elapsed / args.steps) / 1e9 * world, 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    free_state()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sample):
+    """The CPU oracle (port of the reference algorithms) on a forest patch of the same density,
+    timed on this host: as-reference = 1 thread (calculations.rs:332 is a sequential iterator)."""
+    from oracle import oracle as O
+    from treee_amd import synth
+
+    O.build()
+    plot = PLOT * (sample / 15_000_000) ** 0.5
+    pts, seg = synth.forest_cloud(sample, plot=plot)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    mn = pts.min(0)
+    keys = O.morton_keys(pts, mn, float((pts.max(0) - mn).max()))
+    sk, perm = O.sort_keys(keys)
+    O.octree_build(sk, 256, 256)
+    t1 = time.perf_counter()
+    curve = O.curvature(pts, K, F32_MAX, threads=1)
+    t2 = time.perf_counter()
+    val = np.array([O.map_to_u32(v) for v in curve[:1]], np.uint32)  # noqa: F841 (elementwise, negligible)
+    view = np.eye(4, dtype=np.float32)
+    view[2, 3] = -(100.0)
+    O.splat(pts, seg, np.ascontiguousarray(view.T).reshape(16), O.perspective(W / H, 45.0 * 2 * np.pi / 360.0, 0.1, 1e4), 0.1, 0, 0xFFFFFFFF, W, H)
+    t3 = time.perf_counter()
+    O.curvature(pts, K, F32_MAX, threads=cores)
+    t4 = time.perf_counter()
+    one = sample / (t3 - t0) / 1e6
+    return {
+        "value": round(one, 4),
+        "unit": "Mpoints/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{sample}-point forest patch at the 15M config's density (375 pts/m^2); sort+octree {t1 - t0:.2f}s, KDTree build + 31-NN + curvature {t2 - t1:.2f}s (1 thread, as the reference), software splat {t3 - t2:.2f}s",
+        "knn_curve_all_cores": {"cores": cores, "Mpoints_per_s": round(sample / (t4 - t3) / 1e6, 4)},
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -59,7 +59,8 @@ const char *treee_last_error(void);
 int32_t treee_device_count(int32_t *count_out);
 
 /* ---- context ------------------------------------------------------------------------- */
-/* hip_stream: an existing hipStream_t (e.g. torch's current stream) or NULL to create one. */
+/* hip_stream: the hipStream_t all work of this context is enqueued on (e.g. torch's current
+ * stream); NULL is HIP's legacy default stream, as everywhere in HIP. */
 int32_t treee_ctx_create(int32_t device, void *hip_stream, treee_ctx **out);
 int32_t treee_ctx_destroy(treee_ctx *ctx);
 int32_t treee_ctx_sync(treee_ctx *ctx);
@@ -71,6 +72,9 @@ int32_t treee_ctx_reserve(treee_ctx *ctx, uint64_t bytes);
  * (treee/src/calculations.rs:396-407).  Copies the coordinates; n == 0 -> TREEE_ERR_EMPTY. */
 int32_t treee_knn_build(const float *xyz_aos, uint64_t n, treee_knn **out);
 int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, treee_knn **out);
+/* kNN structure over the cloud an octree has already Morton-sorted (shares the sorted arrays
+ * by reference count: one sort feeds both; either handle may be freed first) */
+int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_knn **out);
 int32_t treee_knn_free(treee_knn *t);
 int32_t treee_knn_len(const treee_knn *t, uint64_t *n_out);
 

@@ -50,6 +50,7 @@ SYMBOLS = {
     "treee_ctx_reserve": (_i32, [_vp, _u64]),
     "treee_knn_build": (_i32, [_vp, _u64, _pp]),
     "treee_knn_build_dev": (_i32, [_vp, _vp, _u64, _pp]),
+    "treee_knn_from_octree_dev": (_i32, [_vp, _vp, _pp]),
     "treee_knn_free": (_i32, [_vp]),
     "treee_knn_len": (_i32, [_vp, C.POINTER(_u64)]),
     "treee_knn_query_batch": (_i32, [_vp, _vp, _u64, _u32, _f32, _vp, _vp]),

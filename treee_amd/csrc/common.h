@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../include/treee_hip.h"
@@ -120,8 +121,15 @@ struct SortedCloud {
 	uint32_t *d_keys = nullptr;  // sorted
 	uint32_t *d_perm = nullptr;  // sorted position -> original index
 	float4 *d_sorted = nullptr;  // (x,y,z,bitcast(orig)) sorted
+	int device = 0;
+	SortedCloud() = default;
+	SortedCloud(const SortedCloud &) = delete;
+	SortedCloud &operator=(const SortedCloud &) = delete;
+	~SortedCloud() { release(); }
 	void release();
 };
+// the sorted cloud of an octree can be shared with a kNN structure (one sort, two consumers)
+std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o);
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner,
                            float size, SortedCloud *out);
 

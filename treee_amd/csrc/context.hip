@@ -24,6 +24,11 @@ int32_t default_ctx(treee_ctx **out) {
 		int dev = 0;
 		TREEE_HIP(hipGetDevice(&dev));
 		TREEE_TRY(treee_ctx_create(dev, nullptr, &g_default));
+		// the host-pointer API gets a private non-blocking stream: it synchronises itself
+		hipStream_t s = nullptr;
+		TREEE_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+		g_default->stream = s;
+		g_default->own_stream = true;
 	}
 	*out = g_default;
 	return TREEE_OK;
@@ -104,17 +109,10 @@ int32_t treee_ctx_create(int32_t device, void *hip_stream, treee_ctx **out) {
 	TREEE_HIP(hipSetDevice(device));
 	treee_ctx *c = new treee_ctx;
 	c->device = device;
-	if (hip_stream) {
-		c->stream = (hipStream_t)hip_stream;
-		c->own_stream = false;
-	} else {
-		hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-		if (se != hipSuccess) {
-			delete c;
-			return set_err(TREEE_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
-		}
-		c->own_stream = true;
-	}
+	// the handle is used verbatim; NULL is HIP's legacy default stream (what torch's default
+	// stream is), NOT a request for a private stream
+	c->stream = (hipStream_t)hip_stream;
+	c->own_stream = false;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
 	*out = c;

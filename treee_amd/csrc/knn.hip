@@ -22,7 +22,7 @@
 using namespace treee;
 
 struct treee_knn {
-	SortedCloud sc;
+	std::shared_ptr<SortedCloud> sc = std::make_shared<SortedCloud>();
 	uint32_t nb = 0;       // buckets of 64 points
 	uint32_t P = 1;        // leaves padded to a power of two; node i: children 2i, 2i+1; leaf b = P + b
 	float4 *d_bvh = nullptr; // [2P][2] : (min.xyz,0), (max.xyz,0)
@@ -374,9 +374,9 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	const size_t lds = (size_t)k * 64 * 8 + 64 * 16;
 	if (lds > 160 * 1024) return set_err(TREEE_ERR_UNSUPPORTED, "k=%u exceeds the LDS-resident limit (319)", k);
 	KnnArgs a;
-	a.pts = t->sc.d_sorted;
+	a.pts = t->sc->d_sorted;
 	a.bvh = t->d_bvh;
-	a.n = (uint32_t)t->sc.n;
+	a.n = (uint32_t)t->sc->n;
 	a.nb = t->nb;
 	a.P = t->P;
 	a.q_xyz = nullptr;
@@ -396,9 +396,9 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		TREEE_TRY(ctx->alloc_t(nq, &d_qks));
 		TREEE_TRY(ctx->alloc_t(nq, &d_qo));
 		TREEE_TRY(ctx->alloc_t(nwaves, &d_qs));
-		TREEE_TRY(morton_keys_dev(ctx, d_q, nq, t->sc.corner, t->sc.size, d_qk));
+		TREEE_TRY(morton_keys_dev(ctx, d_q, nq, t->sc->corner, t->sc->size, d_qk));
 		TREEE_TRY(sort_pairs_dev(ctx, d_qk, nullptr, nq, 30, d_qks, d_qo));
-		hipLaunchKernelGGL(k_query_start, dim3(div_up(nwaves, 256)), dim3(256), 0, ctx->stream, t->sc.d_keys, a.n, a.nb, d_qks, a.nq, nwaves, d_qs);
+		hipLaunchKernelGGL(k_query_start, dim3(div_up(nwaves, 256)), dim3(256), 0, ctx->stream, t->sc->d_keys, a.n, a.nb, d_qks, a.nq, nwaves, d_qs);
 		TREEE_LAUNCH_CHECK();
 		a.q_xyz = d_q;
 		a.q_order = d_qo;
@@ -407,6 +407,20 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	if (lds > 64 * 1024)
 		TREEE_HIP(hipFuncSetAttribute((const void *)k_knn_heap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(k_knn_heap, dim3(nwaves), dim3(64), lds, ctx->stream, a);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+int32_t build_bvh(treee_ctx *ctx, treee_knn *t) {
+	const uint64_t n = t->sc->n;
+	t->nb = div_up(n, BUCKET);
+	t->P = 1;
+	while (t->P < t->nb) t->P <<= 1;
+	hipError_t e = hipMalloc((void **)&t->d_bvh, (size_t)t->P * 2 * 2 * sizeof(float4));
+	if (e != hipSuccess) return set_err(TREEE_ERR_NOMEM, "hipMalloc bvh: %s", hipGetErrorString(e));
+	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 4)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, t->d_bvh);
+	for (uint32_t lvl = t->P >> 1; lvl >= 1; lvl >>= 1) // nodes [lvl, 2*lvl)
+		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
 }
@@ -424,26 +438,33 @@ int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, tree
 	TREEE_TRY(ctx->reset());
 	treee_knn *t = new treee_knn;
 	t->device = ctx->device;
-	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, nullptr, 0.0f, &t->sc);
+	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, nullptr, 0.0f, t->sc.get());
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);
 		return rc;
 	}
-	t->nb = div_up(n, BUCKET);
-	t->P = 1;
-	while (t->P < t->nb) t->P <<= 1;
-	hipError_t e = hipMalloc((void **)&t->d_bvh, (size_t)t->P * 2 * 2 * sizeof(float4));
-	if (e != hipSuccess) {
+	rc = build_bvh(ctx, t);
+	if (rc != TREEE_OK) {
 		treee_knn_free(t);
-		return set_err(TREEE_ERR_NOMEM, "hipMalloc bvh: %s", hipGetErrorString(e));
+		return rc;
 	}
-	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 4)), dim3(256), 0, ctx->stream, t->sc.d_sorted, (uint32_t)n, t->nb, t->P, t->d_bvh);
-	for (uint32_t lvl = t->P >> 1; lvl >= 1; lvl >>= 1) // nodes [lvl, 2*lvl)
-		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
-	hipError_t le = hipGetLastError();
-	if (le != hipSuccess) {
+	*out = t;
+	return TREEE_OK;
+}
+
+int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_knn **out) {
+	if (!ctx || !o || !out) return set_err(TREEE_ERR_INVALID, "treee_knn_from_octree_dev: null argument");
+	*out = nullptr;
+	std::shared_ptr<SortedCloud> sc = octree_sorted_cloud(o);
+	if (sc->n == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	treee_knn *t = new treee_knn;
+	t->device = ctx->device;
+	t->sc = sc; // one Morton sort, two consumers
+	int32_t rc = build_bvh(ctx, t);
+	if (rc != TREEE_OK) {
 		treee_knn_free(t);
-		return set_err(TREEE_ERR_HIP, "knn build launch: %s", hipGetErrorString(le));
+		return rc;
 	}
 	*out = t;
 	return TREEE_OK;
@@ -469,7 +490,7 @@ int32_t treee_knn_free(treee_knn *t) {
 	if (!t) return TREEE_OK;
 	(void)hipSetDevice(t->device);
 	(void)hipDeviceSynchronize();
-	t->sc.release();
+	t->sc.reset();
 	if (t->d_bvh) (void)hipFree(t->d_bvh);
 	delete t;
 	return TREEE_OK;
@@ -477,7 +498,7 @@ int32_t treee_knn_free(treee_knn *t) {
 
 int32_t treee_knn_len(const treee_knn *t, uint64_t *n_out) {
 	if (!t || !n_out) return set_err(TREEE_ERR_INVALID, "treee_knn_len: null argument");
-	*n_out = t->sc.n;
+	*n_out = t->sc->n;
 	return TREEE_OK;
 }
 
@@ -494,14 +515,14 @@ int32_t treee_knn_self_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float
 	if (!ctx || !t) return set_err(TREEE_ERR_INVALID, "treee_knn_self_dev: null argument");
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
-	return launch_knn(ctx, t, nullptr, t->sc.n, k, max_dist_sq, d_dist, d_index, d_counts, nullptr);
+	return launch_knn(ctx, t, nullptr, t->sc->n, k, max_dist_sq, d_dist, d_index, d_counts, nullptr);
 }
 
 int32_t treee_curvature_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq, float *d_curve) {
 	if (!ctx || !t || !d_curve) return set_err(TREEE_ERR_INVALID, "treee_curvature_dev: null argument");
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
-	return launch_knn(ctx, t, nullptr, t->sc.n, k, max_dist_sq, nullptr, nullptr, nullptr, d_curve);
+	return launch_knn(ctx, t, nullptr, t->sc->n, k, max_dist_sq, nullptr, nullptr, nullptr, d_curve);
 }
 
 int32_t treee_map_to_u32_dev(treee_ctx *ctx, const float *d_in, uint64_t n, uint32_t *d_out) {
@@ -625,13 +646,13 @@ extern "C" int32_t treee_knn_radius(const treee_knn *t, const float q[3], float 
 	TREEE_TRY(default_ctx(&ctx));
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
-	const uint32_t n = (uint32_t)t->sc.n;
+	const uint32_t n = (uint32_t)t->sc->n;
 	uint32_t *d_counter = nullptr, *d_db = nullptr, *d_pos = nullptr;
 	TREEE_TRY(ctx->alloc_t(1, &d_counter));
 	TREEE_TRY(ctx->alloc_t(n, &d_db));
 	TREEE_TRY(ctx->alloc_t(n, &d_pos));
 	TREEE_HIP(hipMemsetAsync(d_counter, 0, 4, ctx->stream));
-	hipLaunchKernelGGL(k_radius_collect, dim3(div_up(t->nb, 4)), dim3(256), 0, ctx->stream, t->sc.d_sorted, t->d_bvh, n, t->nb, t->P,
+	hipLaunchKernelGGL(k_radius_collect, dim3(div_up(t->nb, 4)), dim3(256), 0, ctx->stream, t->sc->d_sorted, t->d_bvh, n, t->nb, t->P,
 	                   q[0], q[1], q[2], max_bits(max_dist_sq), d_counter, n, d_db, d_pos);
 	TREEE_LAUNCH_CHECK();
 	uint32_t m = 0;
@@ -650,7 +671,7 @@ extern "C" int32_t treee_knn_radius(const treee_knn *t, const float q[3], float 
 	const uint32_t w = (uint32_t)(cap < m ? cap : m);
 	treee_entry *d_ent = nullptr;
 	TREEE_TRY(ctx->alloc_t(w, &d_ent));
-	hipLaunchKernelGGL(k_radius_emit, dim3(div_up(w, 256)), dim3(256), 0, ctx->stream, d_db2, d_pos2, t->sc.d_sorted, w, d_ent);
+	hipLaunchKernelGGL(k_radius_emit, dim3(div_up(w, 256)), dim3(256), 0, ctx->stream, d_db2, d_pos2, t->sc->d_sorted, w, d_ent);
 	TREEE_LAUNCH_CHECK();
 	TREEE_HIP(hipMemcpyAsync(out, d_ent, (size_t)w * sizeof(treee_entry), hipMemcpyDeviceToHost, ctx->stream));
 	TREEE_HIP(hipStreamSynchronize(ctx->stream));

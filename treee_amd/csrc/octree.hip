@@ -11,7 +11,7 @@
 using namespace treee;
 
 struct treee_octree {
-	SortedCloud sc;
+	std::shared_ptr<SortedCloud> sc = std::make_shared<SortedCloud>();
 	treee_octree_node *d_nodes = nullptr;
 	uint64_t n_nodes = 0, nodes_cap = 0;
 	uint32_t *d_leaf = nullptr;
@@ -150,7 +150,7 @@ int32_t grow_nodes(treee_ctx *ctx, treee_octree *o, uint64_t need) {
 }
 
 int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
-	const uint64_t n = o->sc.n;
+	const uint64_t n = o->sc->n;
 	if (n == 0) return TREEE_OK;
 	hipStream_t st = ctx->stream;
 	TREEE_TRY(grow_nodes(ctx, o, 4096));
@@ -165,7 +165,7 @@ int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 		TREEE_TRY(ctx->alloc_t(lvl_count, &d_off));
 		TREEE_TRY(ctx->alloc_t((size_t)lvl_count * 8, &d_bounds));
 		const uint32_t grid = div_up((uint64_t)lvl_count * 8, 256);
-		hipLaunchKernelGGL(k_oct_split, dim3(grid), dim3(256), 0, st, o->sc.d_keys, o->d_nodes, lvl_begin, lvl_count, o->leaf_cap, d_cnt, d_bounds);
+		hipLaunchKernelGGL(k_oct_split, dim3(grid), dim3(256), 0, st, o->sc->d_keys, o->d_nodes, lvl_begin, lvl_count, o->leaf_cap, d_cnt, d_bounds);
 		TREEE_LAUNCH_CHECK();
 		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_cnt, d_off, lvl_count, d_total));
 		uint32_t total = 0;
@@ -200,6 +200,10 @@ int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 
 } // namespace
 
+namespace treee {
+std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o) { return o->sc; }
+} // namespace treee
+
 extern "C" {
 
 int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3], float size,
@@ -212,7 +216,7 @@ int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, con
 	o->device = ctx->device;
 	o->leaf_cap = leaf_cap ? leaf_cap : 256;
 	o->lod_cap = lod_cap ? lod_cap : 256;
-	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, corner, size, &o->sc);
+	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, corner, size, o->sc.get());
 	if (rc == TREEE_OK) rc = build_octree(ctx, o);
 	if (rc != TREEE_OK) {
 		treee_octree_free(o);
@@ -240,7 +244,7 @@ int32_t treee_octree_free(treee_octree *o) {
 	if (!o) return TREEE_OK;
 	(void)hipSetDevice(o->device);
 	(void)hipDeviceSynchronize();
-	o->sc.release();
+	o->sc.reset();
 	if (o->d_nodes) (void)hipFree(o->d_nodes);
 	if (o->d_leaf) (void)hipFree(o->d_leaf);
 	if (o->d_lod) (void)hipFree(o->d_lod);
@@ -250,11 +254,11 @@ int32_t treee_octree_free(treee_octree *o) {
 
 int32_t treee_octree_info_get(const treee_octree *o, treee_octree_info *info) {
 	if (!o || !info) return set_err(TREEE_ERR_INVALID, "treee_octree_info_get: null argument");
-	info->n_points = o->sc.n;
+	info->n_points = o->sc->n;
 	info->n_nodes = o->n_nodes;
 	info->n_lod = o->n_lod;
-	for (int a = 0; a < 3; ++a) info->corner[a] = o->sc.corner[a];
-	info->size = o->sc.size;
+	for (int a = 0; a < 3; ++a) info->corner[a] = o->sc->corner[a];
+	info->size = o->sc->size;
 	info->leaf_cap = o->leaf_cap;
 	info->lod_cap = o->lod_cap;
 	return TREEE_OK;
@@ -262,12 +266,12 @@ int32_t treee_octree_info_get(const treee_octree *o, treee_octree_info *info) {
 
 static int32_t oct_array(const treee_octree *o, int32_t what, const void **p, uint64_t *bytes) {
 	switch (what) {
-	case TREEE_OCT_KEYS: *p = o->sc.d_keys; *bytes = o->sc.n * 4; break;
-	case TREEE_OCT_PERM: *p = o->sc.d_perm; *bytes = o->sc.n * 4; break;
+	case TREEE_OCT_KEYS: *p = o->sc->d_keys; *bytes = o->sc->n * 4; break;
+	case TREEE_OCT_PERM: *p = o->sc->d_perm; *bytes = o->sc->n * 4; break;
 	case TREEE_OCT_NODES: *p = o->d_nodes; *bytes = o->n_nodes * sizeof(treee_octree_node); break;
-	case TREEE_OCT_LEAF: *p = o->d_leaf; *bytes = o->sc.n * 4; break;
+	case TREEE_OCT_LEAF: *p = o->d_leaf; *bytes = o->sc->n * 4; break;
 	case TREEE_OCT_LOD: *p = o->d_lod; *bytes = o->n_lod * 4; break;
-	case TREEE_OCT_SORTED_XYZ: *p = o->sc.d_sorted; *bytes = o->sc.n * 16; break;
+	case TREEE_OCT_SORTED_XYZ: *p = o->sc->d_sorted; *bytes = o->sc->n * 16; break;
 	default: return set_err(TREEE_ERR_INVALID, "unknown octree array id %d", what);
 	}
 	return TREEE_OK;

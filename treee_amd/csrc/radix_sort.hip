@@ -358,6 +358,10 @@ int32_t gather_sorted_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_
 }
 
 void SortedCloud::release() {
+	if (d_keys || d_perm || d_sorted) {
+		(void)hipSetDevice(device);
+		(void)hipDeviceSynchronize();
+	}
 	if (d_keys) (void)hipFree(d_keys);
 	if (d_perm) (void)hipFree(d_perm);
 	if (d_sorted) (void)hipFree(d_sorted);
@@ -367,6 +371,7 @@ void SortedCloud::release() {
 
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc) {
 	sc->n = n;
+	sc->device = ctx->device;
 	if (n >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per shard", (unsigned long long)n);
 	if (corner && size > 0.0f) {
 		for (int a = 0; a < 3; ++a) sc->corner[a] = corner[a];

@@ -1,0 +1,128 @@
+"""Spatial sharding of one cloud over the GPUs of a node.
+
+One process per GPU.  The cloud is cut into x/z tiles (y = height is never cut, like the
+forest plots of section 8 D); every rank runs the whole pipeline on its own tile.  The only
+data-path exchange is the ghost-point all-gather: points within `halo` metres of a tile face
+are gathered (padded to the largest contribution -- RCCL all-gather needs equal counts) and
+every rank keeps the ghosts that fall inside its own dilated tile.  xGMI is point-to-point and
+the halo volume is a few MB per rank (0.3 M points at 150 M / 8 GPUs), so one padded
+all-gather is far below link bandwidth; no other collective touches point data.
+
+Exactness with the reference's unbounded radius (max_distance = f32::MAX,
+treee/src/calculations.rs:279): a query's result is exact iff its k-th neighbour distance is
+<= its distance to the outer rim of the halo; `halo_is_sufficient` checks exactly that and the
+caller widens the halo and repeats otherwise (1 round on forest data).
+
+The frame buffer is combined with an element-wise MIN all-reduce on the packed
+(depth_bits << 32 | index) words, which is what a single-GPU draw of the whole cloud would
+have produced (indices are made globally unique with index_base).
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def tile_grid(world_size):
+    """tiles along x and z: 1->1x1, 2->2x1, 4->2x2, 8->4x2 (SURVEY.md 8E example)."""
+    gx = 1
+    while gx * gx < world_size:
+        gx *= 2
+    gz = max(1, world_size // gx)
+    if gx * gz != world_size:  # non power-of-two world: a single row
+        gx, gz = world_size, 1
+    return gx, gz
+
+
+def tile_origin(rank, world_size, plot):
+    """centre (x, z) of rank's tile when every tile is a plot x plot square."""
+    gx, gz = tile_grid(world_size)
+    ix, iz = rank % gx, rank // gx
+    return ((ix - (gx - 1) / 2.0) * plot, (iz - (gz - 1) / 2.0) * plot)
+
+
+def tile_bounds(rank, world_size, plot):
+    ox, oz = tile_origin(rank, world_size, plot)
+    return (ox - plot / 2.0, ox + plot / 2.0, oz - plot / 2.0, oz + plot / 2.0)
+
+
+def _interior_faces(rank, world_size):
+    """which of the 4 faces (x-, x+, z-, z+) touch another tile."""
+    gx, gz = tile_grid(world_size)
+    ix, iz = rank % gx, rank // gx
+    return (ix > 0, ix < gx - 1, iz > 0, iz < gz - 1)
+
+
+def select_boundary(points, bounds, faces, halo):
+    """points of this tile within `halo` of a face shared with a neighbour tile."""
+    x0, x1, z0, z1 = bounds
+    x, z = points[:, 0], points[:, 2]
+    m = torch.zeros(points.shape[0], dtype=torch.bool, device=points.device)
+    if faces[0]:
+        m |= x < x0 + halo
+    if faces[1]:
+        m |= x >= x1 - halo
+    if faces[2]:
+        m |= z < z0 + halo
+    if faces[3]:
+        m |= z >= z1 - halo
+    return m
+
+
+def exchange_ghosts(points, bounds, halo, rank, world_size, group=None):
+    """the ghost-point all-gather.  Returns the ghosts (float32 [g,3]) that lie inside this
+    rank's tile dilated by `halo` (own points excluded)."""
+    if world_size == 1:
+        return points[:0]
+    faces = _interior_faces(rank, world_size)
+    mine = points[select_boundary(points, bounds, faces, halo)].contiguous()
+    count = torch.tensor([mine.shape[0]], dtype=torch.int64, device=points.device)
+    counts = [torch.zeros_like(count) for _ in range(world_size)]
+    dist.all_gather(counts, count, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    send = torch.zeros((cap, 3), dtype=torch.float32, device=points.device)
+    send[: mine.shape[0]] = mine
+    recv = torch.empty((world_size, cap, 3), dtype=torch.float32, device=points.device)
+    dist.all_gather_into_tensor(recv.view(world_size * cap, 3), send, group=group) if hasattr(dist, "all_gather_into_tensor") and points.is_cuda else _gather_list(recv, send, world_size, group)
+    x0, x1, z0, z1 = bounds
+    keep = []
+    for r in range(world_size):
+        if r == rank or counts[r] == 0:
+            continue
+        g = recv[r, : counts[r]]
+        inside = (g[:, 0] >= x0 - halo) & (g[:, 0] < x1 + halo) & (g[:, 2] >= z0 - halo) & (g[:, 2] < z1 + halo)
+        keep.append(g[inside])
+    return torch.cat(keep) if keep else points[:0]
+
+
+def _gather_list(recv, send, world_size, group):
+    parts = [torch.empty_like(send) for _ in range(world_size)]
+    dist.all_gather(parts, send, group=group)
+    for r in range(world_size):
+        recv[r] = parts[r]
+
+
+def halo_is_sufficient(points, kth_dist_sq, bounds, halo, rank, world_size, group=None):
+    """True on every rank iff every own query's k-th neighbour lies inside the region the halo
+    covers: sqrt(d_k) <= distance to the nearest shared face + halo."""
+    if world_size == 1:
+        return True
+    faces = _interior_faces(rank, world_size)
+    x0, x1, z0, z1 = bounds
+    x, z = points[:, 0], points[:, 2]
+    inf = torch.full_like(x, math.inf)
+    reach = torch.minimum(
+        torch.minimum(x - x0 if faces[0] else inf, x1 - x if faces[1] else inf),
+        torch.minimum(z - z0 if faces[2] else inf, z1 - z if faces[3] else inf),
+    ) + halo
+    bad = (torch.sqrt(kth_dist_sq.to(torch.float64)) > reach.to(torch.float64)).any().to(torch.int32).reshape(1)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    return int(bad.item()) == 0
+
+
+def reduce_packed_min(packed, group=None):
+    """element-wise MIN of the packed (depth_bits << 32 | index) frame buffers of all ranks.
+    depth < 1.0 keeps the sign bit clear, so the signed int64 order equals the unsigned one."""
+    dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)
+    return packed

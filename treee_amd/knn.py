@@ -43,6 +43,16 @@ class KDTree:
         self._h = h
         return self
 
+    @classmethod
+    def from_octree(cls, octree, ctx=None):
+        """kNN structure over the cloud `octree` has already Morton-sorted (no second sort)."""
+        self = object.__new__(cls)
+        self.ctx = ctx or octree.ctx or default_context()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().treee_knn_from_octree_dev(self.ctx.handle, octree._h, C.byref(h)))
+        self._h, self.n, self.device = h, int(octree.n_points), self.ctx.device
+        return self
+
     def __len__(self):
         return self.n
 
