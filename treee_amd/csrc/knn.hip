@@ -19,6 +19,8 @@
 // bit-identical to the reference; indices are identical whenever distances are distinct.
 #include "common.h"
 
+#include <cstdlib>
+
 using namespace treee;
 
 struct treee_knn {
@@ -175,6 +177,7 @@ struct KnnArgs {
 	uint32_t *out_index;
 	uint32_t *out_count;
 	float *out_curve;
+	uint32_t *stats; // optional [4]: buckets scanned, flushes, nodes tested, waves
 };
 
 // one wave per workgroup; dynamic LDS = k*64*8 (heap) + 64*16 (candidate tile)
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(64) void k_knn_heap(KnnArgs a) {
 	}
 	uint32_t wd = a.maxbits, wp = 0u; // root = current worst
 
-	auto scan_bucket = [&](uint32_t b) {
+	auto scan_bucket = [&](uint32_t b) __attribute__((always_inline)) {
 		const uint32_t base = b * BUCKET;
 		if (base >= a.n) return;
 		const uint32_t cnt = (a.n - base) < (uint32_t)BUCKET ? (a.n - base) : (uint32_t)BUCKET;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(64) void k_knn_heap(KnnArgs a) {
 		__syncthreads();
 	};
 
-	auto box_hit = [&](uint32_t node) -> bool {
+	auto box_hit = [&](uint32_t node) __attribute__((always_inline)) -> bool {
 		const float4 lo = a.bvh[2ull * node + 0], hi = a.bvh[2ull * node + 1];
 		const float dx = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.0f);
 		const float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.0f);
@@ -304,6 +307,386 @@ __global__ __launch_bounds__(64) void k_knn_heap(KnnArgs a) {
 			for (int x = 0; x < 3; ++x)
 #pragma unroll
 				for (int y = 0; y < 3; ++y) var[x][y] += df[x] * df[y];
+		}
+#pragma unroll
+		for (int x = 0; x < 3; ++x)
+#pragma unroll
+			for (int y = 0; y < 3; ++y) var[x][y] /= len;
+		float eig[3];
+		fast_eigenvalues(var, eig);
+		a.out_curve[row] = (3.0f * eig[2]) / (eig[0] + eig[1] + eig[2]);
+	}
+}
+
+// ---- k <= 32: per-lane sorted top-32 in VGPRs, candidate buffer in LDS, bitonic networks ----------
+// The LDS heap above serialises on dependent ds_read chains (one sift-down = ~10 LDS round
+// trips).  Here each lane keeps its 32 best keys (distance bits << 32 | sorted position) sorted
+// in 64 VGPRs.  Candidates that beat the lane's current 32nd key are only appended to a per-lane
+// LDS buffer ([slot][lane], conflict-free); when any lane's buffer is half full the whole wave
+// sorts its buffers with a 32-input bitonic network, takes min(L[i], B[31-i]) -- the 32 smallest
+// of the union, a bitonic sequence -- and re-sorts with a 5-stage bitonic merge.  No data-
+// dependent loop, no divergence, no LDS latency chain; ~350 compare-exchanges per flush.
+constexpr int SK = 32;          // list size (k <= 32 uses the first k)
+constexpr int SBUF = 32;        // buffer slots per lane
+constexpr int SCHUNK = 16;      // candidates scanned between flush checks
+// Keys are (distance bits + KEY_BIAS) << 32 | sorted position.  Distances are >= +0, so the
+// biased high word lies in [0x00100000, 0x7F900000]: read as an IEEE double every key is a
+// positive NORMAL number, and for positive doubles the numeric order equals the unsigned order
+// of the bit patterns.  A compare-exchange is therefore v_min_f64 + v_max_f64 (2 VALU instead
+// of a 64-bit compare + 4 selects); min/max return one operand unchanged, so bits survive.
+constexpr uint32_t KEY_BIAS = 0x00100000u;
+constexpr unsigned long long KEY_MAX = 0x7FEFFFFFFFFFFFFFull; // largest finite double > every key
+
+__device__ __forceinline__ double key_make(uint32_t db, uint32_t pos) {
+	return __longlong_as_double((long long)(((unsigned long long)(db + KEY_BIAS) << 32) | (unsigned long long)pos));
+}
+__device__ __forceinline__ uint32_t key_db(double k) { return (uint32_t)((unsigned long long)__double_as_longlong(k) >> 32) - KEY_BIAS; }
+__device__ __forceinline__ uint32_t key_pos(double k) { return (uint32_t)(unsigned long long)__double_as_longlong(k); }
+
+__device__ __forceinline__ void cmpx(double &a, double &b) { // a <= b afterwards
+	double lo, hi;
+	asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b));
+	a = lo;
+	b = hi;
+}
+__device__ __forceinline__ double key_min(double a, double b) {
+	double r;
+	asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
+template <int N> __device__ __forceinline__ void bitonic_sort(double (&v)[N]) {
+#pragma unroll
+	for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+		for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+			for (int i = 0; i < N; ++i) {
+				const int l = i ^ j;
+				if (l > i) {
+					if ((i & k) == 0)
+						cmpx(v[i], v[l]);
+					else
+						cmpx(v[l], v[i]);
+				}
+			}
+		}
+	}
+}
+
+template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) { // v bitonic -> ascending
+#pragma unroll
+	for (int j = N >> 1; j > 0; j >>= 1) {
+#pragma unroll
+		for (int i = 0; i < N; ++i) {
+			const int l = i ^ j;
+			if (l > i) cmpx(v[i], v[l]);
+		}
+	}
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int LIST_CAP = 512;   // candidate buckets per wave; more -> packet-traversal fallback
+constexpr int FRONT_CAP = 1024; // BFS frontier (aliases the candidate buffer, which is empty then)
+
+__global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
+	__shared__ __attribute__((aligned(16))) float tile[3][BUCKET]; // SoA candidate tile (x[], y[], z[])
+	__shared__ uint32_t buf[2 * SBUF * 64]; // [pos | distance bits][slot][lane]: conflict-free per slot
+	__shared__ uint32_t s_list[LIST_CAP];
+	const int lane = threadIdx.x;
+	const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+	const uint32_t slot = blockIdx.x * 64u + lane;
+	const bool live = slot < a.nq;
+	float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+	uint32_t row = 0, start;
+	if (a.q_xyz) {
+		if (live) {
+			row = a.q_order[slot];
+			qx = a.q_xyz[3ull * row + 0];
+			qy = a.q_xyz[3ull * row + 1];
+			qz = a.q_xyz[3ull * row + 2];
+		}
+		start = a.q_start[blockIdx.x];
+	} else {
+		if (live) {
+			const float4 p = a.pts[slot];
+			qx = p.x;
+			qy = p.y;
+			qz = p.z;
+			row = __float_as_uint(p.w);
+		}
+		start = blockIdx.x;
+	}
+	// dead lanes never pass the filter: NaN query -> NaN distance
+	if (!live) qx = __uint_as_float(0x7FC00000u);
+	const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+
+	double L[SK]; // FixedSet::new (best_set.rs:20-28): (max_distance, invalid)
+#pragma unroll
+	for (int i = 0; i < SK; ++i) L[i] = key_make(a.maxbits, 0u);
+	uint32_t thr = a.maxbits; // distance bits of the current 32nd best
+	// byte offset of this lane's next free buffer slot (slot stride 256 B); the buffer is appended
+	// to without branches: every candidate is written, the offset only advances if it passed
+	const uint32_t wofs0 = (uint32_t)lane * 4u;
+	uint32_t wofs = wofs0;
+	constexpr uint32_t DB_OFS = SBUF * 64 * 4; // distance-bits plane behind the position plane
+	uint32_t st_buckets = 1, st_flush = 0, st_nodes = 0;
+
+	auto flush = [&]() __attribute__((always_inline)) {
+		double B[SK];
+#pragma unroll
+		for (int s = 0; s < SK; ++s) {
+			const uint32_t pos = buf[s * 64 + lane], db = buf[SBUF * 64 + s * 64 + lane];
+			B[s] = wofs0 + (uint32_t)s * 256u < wofs ? key_make(db, pos) : __longlong_as_double((long long)KEY_MAX);
+		}
+		bitonic_sort<SK>(B);
+#pragma unroll
+		for (int i = 0; i < SK; ++i) L[i] = key_min(L[i], B[SK - 1 - i]); // 32 smallest of the union, bitonic
+		bitonic_merge<SK>(L);
+		thr = key_db(L[SK - 1]);
+		st_flush++;
+		wofs = wofs0;
+	};
+
+	const float nanv = __uint_as_float(0x7FC00000u);
+	auto load_bucket = [&](uint32_t b) __attribute__((always_inline)) -> float4 {
+		const uint32_t i = b * BUCKET + lane;
+		return i < a.n ? a.pts[i] : make_float4(nanv, nanv, nanv, 0.0f); // padding never passes
+	};
+	auto stage = [&](const float4 &p) __attribute__((always_inline)) {
+		tile[0][lane] = p.x;
+		tile[1][lane] = p.y;
+		tile[2][lane] = p.z;
+		__syncthreads(); // single-wave workgroup: orders the tile write before the broadcasts
+	};
+	// all 64 candidates of the staged tile against this lane's query; packed f32 math, two
+	// candidates per instruction; the append is branch-free (write always, count if it passes)
+	auto scan_tile = [&](uint32_t base) __attribute__((always_inline)) {
+#pragma unroll 1
+		for (int c0 = 0; c0 < BUCKET; c0 += SCHUNK) {
+			if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
+			uint32_t db[SCHUNK];
+#pragma unroll
+			for (int j = 0; j < SCHUNK; j += 2) {
+				const v2f cx = *(const v2f *)&tile[0][c0 + j]; // same address in every lane: LDS broadcast
+				const v2f cy = *(const v2f *)&tile[1][c0 + j];
+				const v2f cz = *(const v2f *)&tile[2][c0 + j];
+				const v2f dx = cx - qx2, dy = cy - qy2, dz = cz - qz2;
+				const v2f d = (dx * dx + dy * dy) + dz * dz; // metric.rs:21-26 (0 + dx*dx == dx*dx exactly)
+				db[j] = __float_as_uint(d.x);
+				db[j + 1] = __float_as_uint(d.y);
+			}
+#pragma unroll
+			for (int j = 0; j < SCHUNK; ++j) { // coarse filter; the merge applies the full (distance, position) order
+				char *w = (char *)buf + wofs;
+				*(uint32_t *)w = base + c0 + j;
+				*(uint32_t *)(w + DB_OFS) = db[j];
+				wofs += db[j] <= thr ? 256u : 0u;
+			}
+		}
+		__syncthreads();
+	};
+	auto scan_bucket = [&](uint32_t b) __attribute__((always_inline)) {
+		if (b * BUCKET >= a.n) return;
+		stage(load_bucket(b));
+		scan_tile(b * BUCKET);
+	};
+	auto lane_box_hit = [&](float lox, float loy, float loz, float hix, float hiy, float hiz) __attribute__((always_inline)) -> bool {
+		const float dx = fmaxf(fmaxf(lox - qx, qx - hix), 0.0f);
+		const float dy = fmaxf(fmaxf(loy - qy, qy - hiy), 0.0f);
+		const float dz = fmaxf(fmaxf(loz - qz, qz - hiz), 0.0f);
+		const float bd = (dx * dx + dy * dy) + dz * dz;
+		return __any(live && __float_as_uint(bd) <= thr);
+	};
+
+	if (start >= a.nb) start = a.nb - 1;
+	scan_bucket(start);
+	if (__any(wofs != wofs0)) flush(); // threshold = 32nd best inside the own bucket
+
+	// ---- candidate buckets by a wave-parallel BFS: one lane per tree node -----------------------
+	// Query box of the wave and its largest threshold bound every lane's search ball, so a node
+	// whose box is farther than that from the query box cannot matter to any lane.  Seeds are the
+	// sibling subtrees along the path from the own bucket to the root (an exact cover).
+	float wlo[3], whi[3];
+	{
+		const float q[3] = {qx, qy, qz};
+#pragma unroll
+		for (int c = 0; c < 3; ++c) {
+			float lo = live ? q[c] : INFINITY, hi = live ? q[c] : -INFINITY;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				lo = fminf(lo, __shfl_xor(lo, o, 64));
+				hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+			}
+			wlo[c] = lo;
+			whi[c] = hi;
+		}
+	}
+	uint32_t tau = live ? thr : 0u;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const uint32_t t = __shfl_xor(tau, o, 64);
+		tau = t > tau ? t : tau;
+	}
+	uint32_t *front = (uint32_t *)buf; // two frontiers of FRONT_CAP nodes alias the (empty) buffer
+	uint32_t cur = 0, m = 0, list_m = 0;
+	for (uint32_t nd = a.P + start; nd > 1u; nd >>= 1) ++m; // tree depth = number of seeds (<= 31)
+	if ((uint32_t)lane < m) front[lane] = ((a.P + start) >> lane) ^ 1u;
+	__syncthreads();
+	bool overflow = false;
+	while (m > 0) {
+		uint32_t next_m = 0;
+		uint32_t *nxt = front + (cur ^ 1u) * FRONT_CAP;
+		for (uint32_t base = 0; base < m; base += 64) {
+			const uint32_t idx = base + lane;
+			const bool valid = idx < m;
+			const uint32_t node = valid ? front[cur * FRONT_CAP + idx] : 1u;
+			const float4 lo = a.bvh[2ull * node + 0], hi = a.bvh[2ull * node + 1];
+			const float dx = fmaxf(fmaxf(lo.x - whi[0], wlo[0] - hi.x), 0.0f);
+			const float dy = fmaxf(fmaxf(lo.y - whi[1], wlo[1] - hi.y), 0.0f);
+			const float dz = fmaxf(fmaxf(lo.z - whi[2], wlo[2] - hi.z), 0.0f);
+			const float bd = (dx * dx + dy * dy) + dz * dz;
+			const bool hit = valid && __float_as_uint(bd) <= tau;
+			const bool leafhit = hit && node >= a.P && (node - a.P) < a.nb;
+			const bool innerhit = hit && node < a.P;
+			const uint64_t bl = __ballot(leafhit), bi = __ballot(innerhit);
+			if (leafhit) {
+				const uint32_t o = list_m + __popcll(bl & lt_mask);
+				if (o < (uint32_t)LIST_CAP) s_list[o] = node - a.P;
+			}
+			if (innerhit) {
+				const uint32_t o = next_m + 2u * __popcll(bi & lt_mask);
+				if (o + 1u < (uint32_t)FRONT_CAP) {
+					nxt[o] = 2u * node;
+					nxt[o + 1u] = 2u * node + 1u;
+				}
+			}
+			list_m += __popcll(bl);
+			next_m += 2u * __popcll(bi);
+			st_nodes++;
+		}
+		if (list_m > (uint32_t)LIST_CAP || next_m > (uint32_t)FRONT_CAP) {
+			overflow = true;
+			break;
+		}
+		cur ^= 1u;
+		m = next_m;
+		__syncthreads();
+	}
+	__syncthreads();
+
+	if (!overflow) {
+		// ---- scan the listed buckets; the next bucket's load is in flight during each scan -------
+		for (uint32_t g = 0; g < list_m; g += 64) {
+			const uint32_t gcount = (list_m - g) < 64u ? (list_m - g) : 64u;
+			const uint32_t my_leaf = (uint32_t)lane < gcount ? s_list[g + lane] : 0u;
+			float4 alo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), ahi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+			if ((uint32_t)lane < gcount) {
+				alo = a.bvh[2ull * (a.P + my_leaf) + 0];
+				ahi = a.bvh[2ull * (a.P + my_leaf) + 1];
+			}
+			// next listed bucket (index >= from) that some lane still needs, judged with the current
+			// threshold (it only ever shrinks, so a stale decision is merely conservative)
+			auto find_next = [&](uint32_t from) __attribute__((always_inline)) -> uint32_t {
+				for (uint32_t j = from; j < gcount; ++j) {
+					const float lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alo.x), j));
+					const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alo.y), j));
+					const float lz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alo.z), j));
+					const float hx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.x), j));
+					const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.y), j));
+					const float hz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.z), j));
+					if (lane_box_hit(lx, ly, lz, hx, hy, hz)) return j;
+				}
+				return gcount;
+			};
+			uint32_t j = find_next(0);
+			float4 pf = make_float4(nanv, nanv, nanv, 0.0f);
+			if (j < gcount) pf = load_bucket((uint32_t)__builtin_amdgcn_readlane((int)my_leaf, j));
+			while (j < gcount) {
+				const uint32_t leaf = (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, j);
+				stage(pf);
+				j = find_next(j + 1);
+				if (j < gcount) pf = load_bucket((uint32_t)__builtin_amdgcn_readlane((int)my_leaf, j));
+				scan_tile(leaf * BUCKET);
+				st_buckets++;
+			}
+		}
+	} else {
+		// ---- fallback (huge search radius): packet traversal, bottom-up from the own bucket -------
+		uint32_t node = a.P + start;
+		while (node > 1u) {
+			const uint32_t root = node ^ 1u;
+			uint32_t i = root;
+			for (;;) {
+				const float4 lo = a.bvh[2ull * i + 0], hi = a.bvh[2ull * i + 1];
+				const bool hit = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+				st_nodes++;
+				if (hit && i < a.P) {
+					i = 2u * i;
+					continue;
+				}
+				if (hit) {
+					scan_bucket(i - a.P);
+					st_buckets++;
+				}
+				while (i != root && (i & 1u)) i >>= 1;
+				if (i == root) break;
+				i += 1u;
+			}
+			node >>= 1;
+		}
+	}
+	if (__any(wofs != wofs0)) flush();
+	if (a.stats && lane == 0) {
+		atomicAdd(&a.stats[0], st_buckets);
+		atomicAdd(&a.stats[1], st_flush);
+		atomicAdd(&a.stats[2], st_nodes);
+		atomicAdd(&a.stats[3], 1u);
+	}
+	if (!live) return;
+
+	const uint32_t k = a.k;
+	uint32_t count = 0;
+#pragma unroll
+	for (int s = 0; s < SK; ++s) count += ((uint32_t)s < k && key_db(L[s]) < a.maxbits) ? 1u : 0u;
+	if (a.out_count) a.out_count[row] = count;
+	if (a.out_dist || a.out_index) {
+#pragma unroll
+		for (int s = 0; s < SK; ++s) {
+			if ((uint32_t)s < k) {
+				const bool ok = (uint32_t)s < count;
+				if (a.out_dist) a.out_dist[(size_t)row * k + s] = __uint_as_float(ok ? key_db(L[s]) : a.maxbits);
+				if (a.out_index) a.out_index[(size_t)row * k + s] = ok ? __float_as_uint(a.pts[key_pos(L[s])].w) : NONE32;
+			}
+		}
+	}
+	if (a.out_curve) { // treee/src/calculations.rs:342-368, neighbours in ascending order
+		const float len = (float)count;
+		float mean[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+		for (int s = 0; s < SK; ++s) {
+			if ((uint32_t)s < count) {
+				const float4 p = a.pts[key_pos(L[s])];
+				mean[0] += p.x;
+				mean[1] += p.y;
+				mean[2] += p.z;
+			}
+		}
+		mean[0] = mean[0] / len;
+		mean[1] = mean[1] / len;
+		mean[2] = mean[2] / len;
+		float var[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+		for (int s = 0; s < SK; ++s) {
+			if ((uint32_t)s < count) {
+				const float4 p = a.pts[key_pos(L[s])];
+				const float df[3] = {p.x - mean[0], p.y - mean[1], p.z - mean[2]};
+#pragma unroll
+				for (int x = 0; x < 3; ++x)
+#pragma unroll
+					for (int y = 0; y < 3; ++y) var[x][y] += df[x] * df[y];
+			}
 		}
 #pragma unroll
 		for (int x = 0; x < 3; ++x)
@@ -389,6 +772,12 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	a.out_index = d_index;
 	a.out_count = d_counts;
 	a.out_curve = d_curve;
+	a.stats = nullptr;
+	static const bool want_stats = getenv("TREEE_KNN_STATS") != nullptr; // diagnostic counters
+	if (want_stats) {
+		TREEE_TRY(ctx->alloc_t(4, &a.stats));
+		TREEE_HIP(hipMemsetAsync(a.stats, 0, 16, ctx->stream));
+	}
 	const uint32_t nwaves = div_up(nq, 64);
 	if (d_q) { // external queries: Morton-sort them so that a wave is spatially compact
 		uint32_t *d_qk = nullptr, *d_qks = nullptr, *d_qo = nullptr, *d_qs = nullptr;
@@ -404,10 +793,21 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		a.q_order = d_qo;
 		a.q_start = d_qs;
 	}
-	if (lds > 64 * 1024)
-		TREEE_HIP(hipFuncSetAttribute((const void *)k_knn_heap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(k_knn_heap, dim3(nwaves), dim3(64), lds, ctx->stream, a);
+	static const bool force_heap = getenv("TREEE_KNN_FORCE_HEAP") != nullptr; // A/B and test hook
+	if (k <= (uint32_t)SK && !force_heap) {
+		hipLaunchKernelGGL(k_knn_sorted32, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+	} else {
+		if (lds > 64 * 1024)
+			TREEE_HIP(hipFuncSetAttribute((const void *)k_knn_heap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		hipLaunchKernelGGL(k_knn_heap, dim3(nwaves), dim3(64), lds, ctx->stream, a);
+	}
 	TREEE_LAUNCH_CHECK();
+	if (a.stats) {
+		uint32_t h[4];
+		TREEE_HIP(hipMemcpyAsync(h, a.stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+		TREEE_HIP(hipStreamSynchronize(ctx->stream));
+		fprintf(stderr, "[treee knn stats] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f\n", h[3], h[0] / (double)h[3], h[1] / (double)h[3], h[2] / (double)h[3]);
+	}
 	return TREEE_OK;
 }
 
