@@ -74,10 +74,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal knobs (NOT used by the driver): several ranks on one GPU over gloo
+    backend = os.environ.get("TREEE_BENCH_BACKEND", "nccl")
+    if os.environ.get("TREEE_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import treee_amd as T
     from treee_amd import distributed as D
@@ -157,6 +164,7 @@ def main():
                 print(f"# halo widened to {halo} m", file=sys.stderr)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -173,7 +181,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        D._all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms = stages.mean_ms()
 

@@ -1,0 +1,127 @@
+"""CPU-only: host-side mirror logic (LAS header/chunking, camera, synthetic clouds) and the
+multi-GPU sharding + ghost exchange on world_size 2 with the gloo backend."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_synth_is_deterministic_and_shardable():
+    from treee_amd import synth
+
+    a, sa = synth.forest_cloud(5000, plot=20.0)
+    b, sb = synth.forest_cloud(5000, plot=20.0)
+    assert np.array_equal(a, b) and np.array_equal(sa, sb)
+    c, sc = synth.forest_cloud(2000, plot=20.0, start=3000)  # a pure function of (seed, index)
+    assert np.array_equal(c, a[3000:]) and np.array_equal(sc, sa[3000:])
+    t, st = synth.forest_cloud_torch(5000, "cpu", plot=20.0)
+    assert np.array_equal(t.numpy(), a) and np.array_equal(st.numpy().astype(np.uint32), sa)
+    assert np.array_equal(a, (np.round(a.astype(np.float64) * 1000) / 1000).astype(np.float32))  # 1 mm lattice
+    assert abs((sa == 0).mean() - 0.2) < 0.03 and a[:, 1].max() < 30 and np.abs(a[:, [0, 2]]).max() < 14
+    u = synth.uniform_cloud(1000)
+    assert u.min() >= -50 and u[:, 1].min() >= 0 and u[:, 1].max() < 30 and u.max() < 50
+
+
+def test_las_header_chunks_and_errors():
+    from treee_amd import synth
+    from treee_amd.laz import CorruptFile, Header, Laz
+
+    ints = np.arange(3 * 120_001, dtype=np.int32).reshape(-1, 3)
+    img = synth.las_bytes(ints, scale=(0.01, 0.01, 0.01), offset=(1.0, 2.0, 3.0), record_length=28, fmt=1, extra_header=52)
+    h = Header(img)
+    assert (h.header_size, h.offset_to_point_data, h.point_data_record_length, h.point_data_record_format) == (427, 427, 28, 1)
+    assert h.number_of_point_records == 120_001  # legacy count overrides when non-zero (laz.rs:279-281)
+    laz = Laz(img)
+    assert laz.total() == 3 and laz.chunks[0] == (427, 50_000) and laz.chunks[2] == (427 + 100_000 * 28, 20_001)  # laz.rs:96-107
+    assert np.allclose(laz.center, (h.min + h.max) / 2)
+    other = Laz(img, center=[1.0, 2.0, 3.0])  # Loading::add passes the first file's world_offset (loading.rs:80)
+    assert other.world_offset.tolist() == [1.0, 2.0, 3.0]
+    with pytest.raises(CorruptFile):
+        Header(img[:200])
+    with pytest.raises(CorruptFile):
+        Header(b"LASX" + img[4:])
+    lazy = bytearray(img)
+    lazy[104] |= 0x80
+    with pytest.raises(NotImplementedError):
+        Laz(bytes(lazy))
+
+
+def test_camera_helpers():
+    import treee_amd as T
+
+    v = T.view_from_transform(T.translation(0, 0, 100.0)).reshape(4, 4).T  # row-major view matrix
+    assert np.allclose(v @ np.array([0, 0, 0, 1.0]), [0, 0, -100.0, 1.0])
+    r = T.view_from_transform(T.rotation_x(-math.pi / 2) @ T.translation(0, 0, 50.0)).reshape(4, 4).T
+    p = r @ np.array([0, 0, 0, 1.0])
+    assert np.allclose(p[:3], [0, 0, -50.0], atol=1e-5)  # looking straight down from y = +50
+    assert T.render.FIELD_OF_VIEW == pytest.approx(math.pi / 4)
+
+
+def test_tile_layout():
+    from treee_amd import distributed as D
+
+    assert [D.tile_grid(n) for n in (1, 2, 4, 8)] == [(1, 1), (2, 1), (2, 2), (4, 2)]
+    b = [D.tile_bounds(r, 8, 200.0) for r in range(8)]
+    assert b[0] == (-400.0, -200.0, -200.0, 0.0) and b[7] == (200.0, 400.0, 0.0, 200.0)
+    area = sum((x1 - x0) * (z1 - z0) for x0, x1, z0, z1 in b)
+    assert area == 8 * 200.0 * 200.0
+    assert D._interior_faces(0, 8) == (False, True, False, True) and D._interior_faces(5, 8) == (True, True, True, False)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ghost_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    plot, halo, n = 20.0, 1.5, 20_000
+    bounds = D.tile_bounds(rank, world, plot)
+    pts, _ = synth.forest_cloud_torch(n, "cpu", plot=plot, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, plot))
+    ghosts = D.exchange_ghosts(pts, bounds, halo, rank, world)
+    # k-th distance stand-ins: tiny -> halo sufficient; huge for one boundary point on rank 1 -> insufficient on ALL ranks
+    small = torch.full((n,), 0.01)
+    ok = D.halo_is_sufficient(pts, small, bounds, halo, rank, world)
+    big = small.clone()
+    if rank == 1:
+        big[torch.argmin(pts[:, 0])] = 25.0
+    bad = D.halo_is_sufficient(pts, big, bounds, halo, rank, world)
+    packed = torch.full((4, 4), (0x3F800000 << 32) | 0xFFFFFFFF, dtype=torch.int64)
+    packed[rank, rank] = (0x3F000000 << 32) | (rank * n + 5)
+    packed[3, 3] = ((0x3E000000 + rank) << 32) | rank
+    D.reduce_packed_min(packed)
+    torch.save({"pts": pts, "ghosts": ghosts, "ok": ok, "bad": bad, "packed": packed}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_ghost_exchange_world2_gloo(tmp_path):
+    from treee_amd import distributed as D
+
+    world, plot, halo = 2, 20.0, 1.5
+    mp.spawn(_ghost_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    for r in range(world):
+        other = res[1 - r]["pts"]
+        x0, x1, z0, z1 = D.tile_bounds(r, world, plot)
+        inside = (other[:, 0] >= x0 - halo) & (other[:, 0] < x1 + halo) & (other[:, 2] >= z0 - halo) & (other[:, 2] < z1 + halo)
+        expect = other[inside]
+        got = res[r]["ghosts"]
+        assert got.shape == expect.shape and got.shape[0] > 100
+        key = lambda t: t[np.lexsort(t.numpy().T[::-1])]  # noqa: E731
+        assert torch.equal(key(got), key(expect))  # exactly the neighbour's points inside the dilated tile
+        assert res[r]["ok"] is True and res[r]["bad"] is False
+        p = res[r]["packed"]
+        assert p[0, 0] == (0x3F000000 << 32) | 5 and p[1, 1] == (0x3F000000 << 32) | (20_000 + 5)
+        assert p[3, 3] == (0x3E000000 << 32) | 0 and p[2, 2] == (0x3F800000 << 32) | 0xFFFFFFFF

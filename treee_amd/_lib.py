@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtreee_hip.so")
+LIB_PATH = os.environ.get("TREEE_HIP_LIB") or os.path.join(_HERE, "lib", "libtreee_hip.so")  # env: A/B builds
 
 TREEE_OK, TREEE_ERR_INVALID, TREEE_ERR_HIP, TREEE_ERR_EMPTY, TREEE_ERR_UNSUPPORTED, TREEE_ERR_NOMEM = range(6)
 _ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "EMPTY", 4: "UNSUPPORTED", 5: "NOMEM"}

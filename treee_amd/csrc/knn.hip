@@ -178,6 +178,8 @@ struct KnnArgs {
 	uint32_t *out_count;
 	float *out_curve;
 	uint32_t *stats; // optional [4]: buckets scanned, flushes, nodes tested, waves
+	uint32_t *thr_io;  // diagnostic: per-slot final threshold (written when thr_seed == 0, read when 1)
+	uint32_t thr_seed;
 };
 
 // one wave per workgroup; dynamic LDS = k*64*8 (heap) + 64*16 (candidate tile)
@@ -327,8 +329,18 @@ __global__ __launch_bounds__(64) void k_knn_heap(KnnArgs a) {
 // of the union, a bitonic sequence -- and re-sorts with a 5-stage bitonic merge.  No data-
 // dependent loop, no divergence, no LDS latency chain; ~350 compare-exchanges per flush.
 constexpr int SK = 32;          // list size (k <= 32 uses the first k)
-constexpr int SBUF = 32;        // buffer slots per lane
-constexpr int SCHUNK = 16;      // candidates scanned between flush checks
+#ifndef TREEE_SBUF
+#define TREEE_SBUF 16
+#endif
+#ifndef TREEE_KNN_WAVES
+#define TREEE_KNN_WAVES 3
+#endif
+constexpr int SBUF = TREEE_SBUF;   // buffer slots per lane (power of two <= SK)
+constexpr int SCHUNK = SBUF / 2;   // candidates scanned between flush checks
+#ifndef TREEE_TRANSPOSE_BELOW
+#define TREEE_TRANSPOSE_BELOW 28
+#endif
+constexpr int TRANSPOSE_BELOW = TREEE_TRANSPOSE_BELOW; // buckets needed by fewer queries are scanned transposed
 // Keys are (distance bits + KEY_BIAS) << 32 | sorted position.  Distances are >= +0, so the
 // biased high word lies in [0x00100000, 0x7F900000]: read as an IEEE double every key is a
 // positive NORMAL number, and for positive doubles the numeric order equals the unsigned order
@@ -386,10 +398,21 @@ template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) {
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Software-pipelined bucket load.  hipcc sinks an ordinary prefetch load below the scan it is
+// meant to overlap (and cannot count loads across the loop back-edge), so the load is issued
+// from inline asm and waited for by hand; the "+v" operand ties every later use to the wait.
+__device__ __forceinline__ v4f issue_load_b128(const float4 *p) {
+	v4f r;
+	asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+	return r;
+}
+__device__ __forceinline__ void wait_load_b128(v4f &r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory"); }
 constexpr int LIST_CAP = 512;   // candidate buckets per wave; more -> packet-traversal fallback
 constexpr int FRONT_CAP = 1024; // BFS frontier (aliases the candidate buffer, which is empty then)
 
-__global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
+__global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a) {
 	__shared__ __attribute__((aligned(16))) float tile[3][BUCKET]; // SoA candidate tile (x[], y[], z[])
 	__shared__ uint32_t buf[2 * SBUF * 64]; // [pos | distance bits][slot][lane]: conflict-free per slot
 	__shared__ uint32_t s_list[LIST_CAP];
@@ -426,25 +449,29 @@ __global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
 #pragma unroll
 	for (int i = 0; i < SK; ++i) L[i] = key_make(a.maxbits, 0u);
 	uint32_t thr = a.maxbits; // distance bits of the current 32nd best
+	if (a.thr_io && a.thr_seed && live) thr = a.thr_io[slot]; // diagnostic lower bound: start from the final answer
 	// byte offset of this lane's next free buffer slot (slot stride 256 B); the buffer is appended
 	// to without branches: every candidate is written, the offset only advances if it passed
 	const uint32_t wofs0 = (uint32_t)lane * 4u;
 	uint32_t wofs = wofs0;
 	constexpr uint32_t DB_OFS = SBUF * 64 * 4; // distance-bits plane behind the position plane
-	uint32_t st_buckets = 1, st_flush = 0, st_nodes = 0;
+	uint32_t st_buckets = 1, st_flush = 0, st_nodes = 0, st_need = 0, st_small = 0;
 
 	auto flush = [&]() __attribute__((always_inline)) {
-		double B[SK];
+		double B[SBUF];
 #pragma unroll
-		for (int s = 0; s < SK; ++s) {
+		for (int s = 0; s < SBUF; ++s) {
 			const uint32_t pos = buf[s * 64 + lane], db = buf[SBUF * 64 + s * 64 + lane];
 			B[s] = wofs0 + (uint32_t)s * 256u < wofs ? key_make(db, pos) : __longlong_as_double((long long)KEY_MAX);
 		}
-		bitonic_sort<SK>(B);
+		bitonic_sort<SBUF>(B);
 #pragma unroll
-		for (int i = 0; i < SK; ++i) L[i] = key_min(L[i], B[SK - 1 - i]); // 32 smallest of the union, bitonic
+		for (int i = SK - SBUF; i < SK; ++i) L[i] = key_min(L[i], B[SK - 1 - i]); // 32 smallest of the union, bitonic
 		bitonic_merge<SK>(L);
-		thr = key_db(L[SK - 1]);
+		{
+			const uint32_t nt = key_db(L[SK - 1]);
+			thr = nt < thr ? nt : thr;
+		}
 		st_flush++;
 		wofs = wofs0;
 	};
@@ -462,7 +489,8 @@ __global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
 	};
 	// all 64 candidates of the staged tile against this lane's query; packed f32 math, two
 	// candidates per instruction; the append is branch-free (write always, count if it passes)
-	auto scan_tile = [&](uint32_t base) __attribute__((always_inline)) {
+	auto scan_tile = [&](uint32_t base, uint64_t lanes) __attribute__((always_inline)) {
+		const bool act = (lanes >> lane) & 1ull; // lanes outside `lanes` must not append (they saw this bucket already)
 #pragma unroll 1
 		for (int c0 = 0; c0 < BUCKET; c0 += SCHUNK) {
 			if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
@@ -482,7 +510,7 @@ __global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
 				char *w = (char *)buf + wofs;
 				*(uint32_t *)w = base + c0 + j;
 				*(uint32_t *)(w + DB_OFS) = db[j];
-				wofs += db[j] <= thr ? 256u : 0u;
+				wofs += (db[j] <= thr && act) ? 256u : 0u;
 			}
 		}
 		__syncthreads();
@@ -490,14 +518,15 @@ __global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
 	auto scan_bucket = [&](uint32_t b) __attribute__((always_inline)) {
 		if (b * BUCKET >= a.n) return;
 		stage(load_bucket(b));
-		scan_tile(b * BUCKET);
+		scan_tile(b * BUCKET, ~0ull);
 	};
-	auto lane_box_hit = [&](float lox, float loy, float loz, float hix, float hiy, float hiz) __attribute__((always_inline)) -> bool {
+	// lanes (queries) whose search ball still reaches the box
+	auto lane_box_hit = [&](float lox, float loy, float loz, float hix, float hiy, float hiz) __attribute__((always_inline)) -> uint64_t {
 		const float dx = fmaxf(fmaxf(lox - qx, qx - hix), 0.0f);
 		const float dy = fmaxf(fmaxf(loy - qy, qy - hiy), 0.0f);
 		const float dz = fmaxf(fmaxf(loz - qz, qz - hiz), 0.0f);
 		const float bd = (dx * dx + dy * dy) + dz * dz;
-		return __any(live && __float_as_uint(bd) <= thr);
+		return __ballot(live && __float_as_uint(bd) <= thr);
 	};
 
 	if (start >= a.nb) start = a.nb - 1;
@@ -588,6 +617,7 @@ __global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
 			}
 			// next listed bucket (index >= from) that some lane still needs, judged with the current
 			// threshold (it only ever shrinks, so a stale decision is merely conservative)
+			uint64_t need = 0; // queries that need the bucket find_next returned
 			auto find_next = [&](uint32_t from) __attribute__((always_inline)) -> uint32_t {
 				for (uint32_t j = from; j < gcount; ++j) {
 					const float lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alo.x), j));
@@ -596,19 +626,75 @@ __global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
 					const float hx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.x), j));
 					const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.y), j));
 					const float hz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.z), j));
-					if (lane_box_hit(lx, ly, lz, hx, hy, hz)) return j;
+					need = lane_box_hit(lx, ly, lz, hx, hy, hz);
+					if (need) return j;
 				}
 				return gcount;
 			};
+			// the record this lane would stage for listed bucket j (clamped address: padding lanes of the
+			// last bucket read a valid record and are replaced by NaN after the wait)
+			auto bucket_ptr = [&](uint32_t jj) __attribute__((always_inline)) -> const float4 * {
+				const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, jj) * BUCKET + lane;
+				return a.pts + (i < a.n ? i : a.n - 1u);
+			};
 			uint32_t j = find_next(0);
-			float4 pf = make_float4(nanv, nanv, nanv, 0.0f);
-			if (j < gcount) pf = load_bucket((uint32_t)__builtin_amdgcn_readlane((int)my_leaf, j));
+			v4f pf = {nanv, nanv, nanv, 0.0f};
+			if (j < gcount) pf = issue_load_b128(bucket_ptr(j));
 			while (j < gcount) {
 				const uint32_t leaf = (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, j);
-				stage(pf);
+				const uint64_t need_cur = need;
+				wait_load_b128(pf); // only this bucket's load is outstanding here
+				const bool inr = leaf * BUCKET + lane < a.n;
+				const float4 cand = make_float4(inr ? pf.x : nanv, inr ? pf.y : nanv, inr ? pf.z : nanv, 0.0f); // this lane's record of bucket `leaf`
+				st_need += (uint32_t)__popcll(need_cur);
+				const bool small = __popcll(need_cur) < TRANSPOSE_BELOW;
+				// order matters: consume this bucket's registers (LDS staging) BEFORE the next load is issued,
+				// otherwise the wait for `cand` also drains the prefetch and exposes its latency
+				if (!small) stage(cand);
 				j = find_next(j + 1);
-				if (j < gcount) pf = load_bucket((uint32_t)__builtin_amdgcn_readlane((int)my_leaf, j));
-				scan_tile(leaf * BUCKET);
+				if (j < gcount) pf = issue_load_b128(bucket_ptr(j)); // in flight during the scan below
+				uint64_t full = ~0ull; // queries to serve with the lane-parallel scan
+				if (small) {
+					// ---- transposed scan: few queries still need this bucket, so lanes = candidates (kept in
+					// registers, no LDS staging) and the loop runs over the needing queries only.  A query
+					// whose buffer lacks room is deferred to the lane-parallel scan below (rare).
+					st_small++;
+					full = 0ull;
+					const uint32_t mypos = leaf * BUCKET + lane;
+					uint64_t todo = need_cur;
+					while (todo) {
+						const int q = __builtin_ctzll(todo);
+						todo &= todo - 1ull;
+						const float sqx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qx), q));
+						const float sqy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qy), q));
+						const float sqz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qz), q));
+						const uint32_t sthr = (uint32_t)__builtin_amdgcn_readlane((int)thr, q);
+						const float dx = cand.x - sqx, dy = cand.y - sqy, dz = cand.z - sqz;
+						const float d = (dx * dx + dy * dy) + dz * dz;
+						const uint32_t db = __float_as_uint(d);
+						const bool pass = db <= sthr; // NaN padding never passes
+						const uint64_t pm = __ballot(pass);
+						if (!pm) continue;
+						const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)wofs, q);
+						const uint32_t room = (uint32_t)SBUF - ((w - (uint32_t)q * 4u) >> 8);
+						const uint32_t npass = (uint32_t)__popcll(pm);
+						if (npass > room) {
+							full |= 1ull << q;
+							continue;
+						}
+						if (pass) {
+							const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+							char *wp = (char *)buf + w + pre * 256u;
+							*(uint32_t *)wp = mypos;
+							*(uint32_t *)(wp + DB_OFS) = db;
+						}
+						wofs = lane == q ? w + npass * 256u : wofs;
+					}
+				}
+				if (full) {
+					if (small) stage(cand); // deferred queries of a transposed bucket (rare)
+					scan_tile(leaf * BUCKET, full);
+				}
 				st_buckets++;
 			}
 		}
@@ -620,7 +706,7 @@ __global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
 			uint32_t i = root;
 			for (;;) {
 				const float4 lo = a.bvh[2ull * i + 0], hi = a.bvh[2ull * i + 1];
-				const bool hit = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+				const bool hit = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) != 0;
 				st_nodes++;
 				if (hit && i < a.P) {
 					i = 2u * i;
@@ -638,11 +724,14 @@ __global__ __launch_bounds__(64) void k_knn_sorted32(KnnArgs a) {
 		}
 	}
 	if (__any(wofs != wofs0)) flush();
+	if (a.thr_io && !a.thr_seed && live) a.thr_io[slot] = thr;
 	if (a.stats && lane == 0) {
 		atomicAdd(&a.stats[0], st_buckets);
 		atomicAdd(&a.stats[1], st_flush);
 		atomicAdd(&a.stats[2], st_nodes);
 		atomicAdd(&a.stats[3], 1u);
+		atomicAdd(&a.stats[4], st_need);
+		atomicAdd(&a.stats[5], st_small);
 	}
 	if (!live) return;
 
@@ -773,10 +862,12 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	a.out_count = d_counts;
 	a.out_curve = d_curve;
 	a.stats = nullptr;
+	a.thr_io = nullptr;
+	a.thr_seed = 0;
 	static const bool want_stats = getenv("TREEE_KNN_STATS") != nullptr; // diagnostic counters
 	if (want_stats) {
-		TREEE_TRY(ctx->alloc_t(4, &a.stats));
-		TREEE_HIP(hipMemsetAsync(a.stats, 0, 16, ctx->stream));
+		TREEE_TRY(ctx->alloc_t(8, &a.stats));
+		TREEE_HIP(hipMemsetAsync(a.stats, 0, 32, ctx->stream));
 	}
 	const uint32_t nwaves = div_up(nq, 64);
 	if (d_q) { // external queries: Morton-sort them so that a wave is spatially compact
@@ -803,10 +894,22 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	}
 	TREEE_LAUNCH_CHECK();
 	if (a.stats) {
-		uint32_t h[4];
-		TREEE_HIP(hipMemcpyAsync(h, a.stats, 16, hipMemcpyDeviceToHost, ctx->stream));
+		uint32_t h[8];
+		TREEE_HIP(hipMemcpyAsync(h, a.stats, 32, hipMemcpyDeviceToHost, ctx->stream));
 		TREEE_HIP(hipStreamSynchronize(ctx->stream));
-		fprintf(stderr, "[treee knn stats] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f\n", h[3], h[0] / (double)h[3], h[1] / (double)h[3], h[2] / (double)h[3]);
+		fprintf(stderr, "[treee knn stats] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f need/bucket=%.2f small-buckets/wave=%.2f\n", h[3], h[0] / (double)h[3],
+		        h[1] / (double)h[3], h[2] / (double)h[3], h[4] / (double)(h[0] - h[3] ? h[0] - h[3] : 1), h[5] / (double)h[3]);
+		static const bool want_ideal = getenv("TREEE_KNN_IDEAL") != nullptr;
+		if (want_ideal && k <= (uint32_t)SK && !d_q) { // lower bound: rerun with every threshold seeded by its final value
+			TREEE_TRY(ctx->alloc_t(nq, &a.thr_io));
+			hipLaunchKernelGGL(k_knn_sorted32, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+			a.thr_seed = 1;
+			TREEE_HIP(hipMemsetAsync(a.stats, 0, 32, ctx->stream));
+			hipLaunchKernelGGL(k_knn_sorted32, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+			TREEE_HIP(hipMemcpyAsync(h, a.stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+			TREEE_HIP(hipStreamSynchronize(ctx->stream));
+			fprintf(stderr, "[treee knn IDEAL] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f\n", h[3], h[0] / (double)h[3], h[1] / (double)h[3], h[2] / (double)h[3]);
+		}
 	}
 	return TREEE_OK;
 }

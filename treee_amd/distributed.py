@@ -23,6 +23,34 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(group=None):
+    """gloo cannot move CUDA tensors: rehearsal runs (several ranks sharing one GPU) stage the
+    collectives through host memory.  With nccl (= RCCL over xGMI) tensors stay in HBM."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, op, group=None):
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def _all_gather_equal(send, world_size, group=None):
+    """all-gather of equally shaped tensors -> [world, ...] on send's device."""
+    if send.is_cuda and not _host_staged(group):
+        recv = torch.empty((world_size,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(recv.view(-1, *send.shape[1:]), send, group=group)
+        return recv
+    h = send.cpu()
+    parts = [torch.empty_like(h) for _ in range(world_size)]
+    dist.all_gather(parts, h, group=group)
+    return torch.stack(parts).to(send.device)
+
+
 def tile_grid(world_size):
     """tiles along x and z: 1->1x1, 2->2x1, 4->2x2, 8->4x2 (SURVEY.md 8E example)."""
     gx = 1
@@ -77,14 +105,11 @@ def exchange_ghosts(points, bounds, halo, rank, world_size, group=None):
     faces = _interior_faces(rank, world_size)
     mine = points[select_boundary(points, bounds, faces, halo)].contiguous()
     count = torch.tensor([mine.shape[0]], dtype=torch.int64, device=points.device)
-    counts = [torch.zeros_like(count) for _ in range(world_size)]
-    dist.all_gather(counts, count, group=group)
-    counts = [int(c.item()) for c in counts]
+    counts = [int(c) for c in _all_gather_equal(count, world_size, group).flatten().tolist()]
     cap = max(max(counts), 1)
     send = torch.zeros((cap, 3), dtype=torch.float32, device=points.device)
     send[: mine.shape[0]] = mine
-    recv = torch.empty((world_size, cap, 3), dtype=torch.float32, device=points.device)
-    dist.all_gather_into_tensor(recv.view(world_size * cap, 3), send, group=group) if hasattr(dist, "all_gather_into_tensor") and points.is_cuda else _gather_list(recv, send, world_size, group)
+    recv = _all_gather_equal(send, world_size, group)  # padded: RCCL all-gather needs equal counts
     x0, x1, z0, z1 = bounds
     keep = []
     for r in range(world_size):
@@ -94,13 +119,6 @@ def exchange_ghosts(points, bounds, halo, rank, world_size, group=None):
         inside = (g[:, 0] >= x0 - halo) & (g[:, 0] < x1 + halo) & (g[:, 2] >= z0 - halo) & (g[:, 2] < z1 + halo)
         keep.append(g[inside])
     return torch.cat(keep) if keep else points[:0]
-
-
-def _gather_list(recv, send, world_size, group):
-    parts = [torch.empty_like(send) for _ in range(world_size)]
-    dist.all_gather(parts, send, group=group)
-    for r in range(world_size):
-        recv[r] = parts[r]
 
 
 def halo_is_sufficient(points, kth_dist_sq, bounds, halo, rank, world_size, group=None):
@@ -117,12 +135,11 @@ def halo_is_sufficient(points, kth_dist_sq, bounds, halo, rank, world_size, grou
         torch.minimum(z - z0 if faces[2] else inf, z1 - z if faces[3] else inf),
     ) + halo
     bad = (torch.sqrt(kth_dist_sq.to(torch.float64)) > reach.to(torch.float64)).any().to(torch.int32).reshape(1)
-    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(bad, dist.ReduceOp.MAX, group)
     return int(bad.item()) == 0
 
 
 def reduce_packed_min(packed, group=None):
     """element-wise MIN of the packed (depth_bits << 32 | index) frame buffers of all ranks.
     depth < 1.0 keeps the sign bit clear, so the signed int64 order equals the unsigned one."""
-    dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)
-    return packed
+    return _all_reduce(packed, dist.ReduceOp.MIN, group)

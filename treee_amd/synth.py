@@ -49,6 +49,13 @@ def _ground(x, z):
     return 0.5 * np.sin(x / 17.0) + 0.5 * np.cos(z / 23.0)
 
 
+def _fold(v, h, xp):
+    """reflect coordinates that overshoot the plot [-h, h) back inside (crowns of edge trees), so
+    that plots tile the plane without overlap and every shard owns exactly its own tile."""
+    v = xp.where(v >= h, 2 * h - v - 1e-3, v)
+    return xp.where(v < -h, -2 * h - v, v)
+
+
 def forest_cloud(n=15_000_000, plot=200.0, seed=SEED_FOREST, origin=(0.0, 0.0), start=0, chunk=4_000_000):
     """cfg 2/3: forest plot of `plot` x `plot` metres centred on `origin` (x, z).
 
@@ -94,9 +101,9 @@ def forest_cloud(n=15_000_000, plot=200.0, seed=SEED_FOREST, origin=(0.0, 0.0), 
         cy = tground[tree] + theight[tree] - cry[tree] + cry[tree] * rr * ct
         is_ground = kind < 0.2
         is_trunk = (~is_ground) & (part < 0.25)
-        x = np.where(is_ground, gx, np.where(is_trunk, kx, cx)) + origin[0]
+        x = _fold(np.where(is_ground, gx, np.where(is_trunk, kx, cx)), plot / 2, np) + origin[0]
         y = np.where(is_ground, gy, np.where(is_trunk, ky, cy))
-        z = np.where(is_ground, gz, np.where(is_trunk, kz, cz)) + origin[1]
+        z = _fold(np.where(is_ground, gz, np.where(is_trunk, kz, cz)), plot / 2, np) + origin[1]
         xyz[lo:hi, 0] = _quantise(x)
         xyz[lo:hi, 1] = _quantise(y)
         xyz[lo:hi, 2] = _quantise(z)
@@ -211,8 +218,8 @@ def forest_cloud_torch(n, device, plot=200.0, seed=SEED_FOREST, origin=(0.0, 0.0
         cy = tground[tree] + theight[tree] - cry[tree] + cry[tree] * rr * ct
         is_ground = kind < 0.2
         is_trunk = (~is_ground) & (part < 0.25)
-        xyz[lo:hi, 0] = q(torch.where(is_ground, gx, torch.where(is_trunk, kx, cx)) + origin[0])
+        xyz[lo:hi, 0] = q(_fold(torch.where(is_ground, gx, torch.where(is_trunk, kx, cx)), plot / 2, torch) + origin[0])
         xyz[lo:hi, 1] = q(torch.where(is_ground, gy, torch.where(is_trunk, ky, cy)))
-        xyz[lo:hi, 2] = q(torch.where(is_ground, gz, torch.where(is_trunk, kz, cz)) + origin[1])
+        xyz[lo:hi, 2] = q(_fold(torch.where(is_ground, gz, torch.where(is_trunk, kz, cz)), plot / 2, torch) + origin[1])
         seg[lo:hi] = torch.where(is_ground, torch.zeros_like(tree), tree + 1).to(torch.int32)
     return xyz, seg
