@@ -118,11 +118,11 @@ def main():
         else:
             cloud = pts
         m = cloud.shape[0]
-        oc = stages.run("keys_sort_octree", lambda: T.Octree(pts, ctx=ctx), record)
-        if m == n:  # no ghosts: the octree's Morton-sorted cloud feeds the kNN structure too
-            tree = stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
-        else:
-            tree = stages.run("knn_build", lambda: T.KDTree.new(cloud, ctx), record)
+        free_state()  # previous step's handles: blocks return to the context pool, stream-ordered, no sync
+        # ONE Morton sort per step: the octree is built over the shard plus its boundary ghosts and the
+        # kNN structure shares that sorted cloud by reference
+        oc = stages.run("keys_sort_octree", lambda: T.Octree(cloud, ctx=ctx), record)
+        tree = stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
         cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
         stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv), record)
         val = stages.run("map_to_u32", lambda: T.map_to_u32_dev(cv[:n], ctx), record)
@@ -147,8 +147,7 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
-        torch.cuda.synchronize()
-        free_state()
+    torch.cuda.synchronize()
 
     # multi-GPU exactness of the unbounded-radius kNN: verify the halo once, outside the timing
     if world > 1:
@@ -173,10 +172,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-        # handles of the previous step are released outside the kernels' critical path:
-        # hipFree synchronises, so free only after the step has been fully enqueued
-        torch.cuda.synchronize()
-        free_state()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/treee_hip.h"
@@ -86,6 +88,16 @@ struct treee_ctx {
 	size_t off = 0; // offset in blocks[cur]
 	int num_cus = 256;
 
+	// pool of persistent blocks (the arrays owned by kNN / octree handles).  Reuse is ordered by
+	// this context's stream, so a block can be handed out again without synchronising.
+	struct PoolBlock {
+		char *p;
+		size_t cap;
+	};
+	std::vector<PoolBlock> pool_idle;
+	std::unordered_map<void *, size_t> pool_live;
+	std::mutex pool_mu;
+
 	int32_t reset();                         // start of an API call: coalesce + rewind
 	int32_t alloc(size_t bytes, void **out); // 256-B aligned
 	template <class T> int32_t alloc_t(size_t count, T **out) {
@@ -113,6 +125,17 @@ int32_t gather_sorted_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_
 int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n,
                                uint32_t *d_total /* device, optional */);
 
+// persistent device blocks for handles: taken from / returned to the owning context's pool.
+// pool_release tolerates a context that has already been destroyed (falls back to hipFree).
+int32_t pool_alloc(treee_ctx *ctx, size_t bytes, void **out);
+void pool_release(treee_ctx *ctx, void *p);
+template <class T> int32_t pool_alloc_t(treee_ctx *ctx, size_t count, T **out) {
+	void *p = nullptr;
+	int32_t rc = pool_alloc(ctx, count * sizeof(T), &p);
+	*out = (T *)p;
+	return rc;
+}
+
 // common per-cloud preparation shared by octree and knn: cube, keys, sort, gather
 struct SortedCloud {
 	uint64_t n = 0;
@@ -122,6 +145,7 @@ struct SortedCloud {
 	uint32_t *d_perm = nullptr;  // sorted position -> original index
 	float4 *d_sorted = nullptr;  // (x,y,z,bitcast(orig)) sorted
 	int device = 0;
+	treee_ctx *owner = nullptr; // context whose pool the arrays came from
 	SortedCloud() = default;
 	SortedCloud(const SortedCloud &) = delete;
 	SortedCloud &operator=(const SortedCloud &) = delete;

@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <mutex>
+#include <set>
 
 namespace treee {
 
@@ -13,6 +14,72 @@ int32_t set_err(int32_t code, const char *fmt, ...) {
 	vsnprintf(g_err, sizeof(g_err), fmt, ap);
 	va_end(ap);
 	return code;
+}
+
+static std::mutex g_live_mu; // contexts that are still alive (handles may outlive their context)
+static std::set<treee_ctx *> g_live;
+constexpr size_t POOL_GRANULE = size_t(1) << 20;
+constexpr size_t POOL_IDLE_LIMIT = size_t(8) << 30; // idle bytes kept per context before trimming
+
+int32_t pool_alloc(treee_ctx *ctx, size_t bytes, void **out) {
+	bytes = ((bytes ? bytes : 1) + POOL_GRANULE - 1) & ~(POOL_GRANULE - 1);
+	{
+		std::lock_guard<std::mutex> lk(ctx->pool_mu);
+		size_t best = SIZE_MAX, best_cap = SIZE_MAX;
+		for (size_t i = 0; i < ctx->pool_idle.size(); ++i) {
+			const size_t cap = ctx->pool_idle[i].cap;
+			if (cap >= bytes && cap <= 2 * bytes && cap < best_cap) {
+				best = i;
+				best_cap = cap;
+			}
+		}
+		if (best != SIZE_MAX) {
+			*out = ctx->pool_idle[best].p;
+			ctx->pool_live[*out] = best_cap;
+			ctx->pool_idle.erase(ctx->pool_idle.begin() + best);
+			return TREEE_OK;
+		}
+	}
+	void *p = nullptr;
+	hipError_t e = hipMalloc(&p, bytes);
+	if (e != hipSuccess) { // give idle blocks back to the driver and retry once
+		{
+			std::lock_guard<std::mutex> lk(ctx->pool_mu);
+			(void)hipStreamSynchronize(ctx->stream);
+			for (auto &b : ctx->pool_idle) (void)hipFree(b.p);
+			ctx->pool_idle.clear();
+		}
+		e = hipMalloc(&p, bytes);
+		if (e != hipSuccess) return set_err(TREEE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+	}
+	std::lock_guard<std::mutex> lk(ctx->pool_mu);
+	ctx->pool_live[p] = bytes;
+	*out = p;
+	return TREEE_OK;
+}
+
+void pool_release(treee_ctx *ctx, void *p) {
+	if (!p) return;
+	std::lock_guard<std::mutex> live(g_live_mu);
+	if (ctx && g_live.count(ctx)) {
+		std::lock_guard<std::mutex> lk(ctx->pool_mu);
+		auto it = ctx->pool_live.find(p);
+		if (it != ctx->pool_live.end()) {
+			ctx->pool_idle.push_back({(char *)p, it->second});
+			ctx->pool_live.erase(it);
+			size_t idle = 0;
+			for (auto &b : ctx->pool_idle) idle += b.cap;
+			while (idle > POOL_IDLE_LIMIT && !ctx->pool_idle.empty()) { // trim oldest first
+				(void)hipStreamSynchronize(ctx->stream);
+				idle -= ctx->pool_idle.front().cap;
+				(void)hipFree(ctx->pool_idle.front().p);
+				ctx->pool_idle.erase(ctx->pool_idle.begin());
+			}
+			return;
+		}
+	}
+	(void)hipDeviceSynchronize(); // owner gone: the block is an ordinary allocation
+	(void)hipFree(p);
 }
 
 static std::mutex g_default_mu;
@@ -115,6 +182,10 @@ int32_t treee_ctx_create(int32_t device, void *hip_stream, treee_ctx **out) {
 	c->own_stream = false;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+	{
+		std::lock_guard<std::mutex> lk(g_live_mu);
+		g_live.insert(c);
+	}
 	*out = c;
 	return TREEE_OK;
 }
@@ -123,6 +194,11 @@ int32_t treee_ctx_destroy(treee_ctx *ctx) {
 	if (!ctx) return TREEE_OK;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	{
+		std::lock_guard<std::mutex> lk(g_live_mu);
+		g_live.erase(ctx); // blocks still held by handles stay valid; they are hipFree'd on release
+	}
+	for (auto &b : ctx->pool_idle) (void)hipFree(b.p);
 	for (auto &b : ctx->blocks) (void)hipFree(b.p);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;

@@ -29,6 +29,7 @@ struct treee_knn {
 	uint32_t P = 1;        // leaves padded to a power of two; node i: children 2i, 2i+1; leaf b = P + b
 	float4 *d_bvh = nullptr; // [2P][2] : (min.xyz,0), (max.xyz,0)
 	int device = 0;
+	treee_ctx *owner = nullptr;
 };
 
 namespace {
@@ -919,8 +920,8 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t) {
 	t->nb = div_up(n, BUCKET);
 	t->P = 1;
 	while (t->P < t->nb) t->P <<= 1;
-	hipError_t e = hipMalloc((void **)&t->d_bvh, (size_t)t->P * 2 * 2 * sizeof(float4));
-	if (e != hipSuccess) return set_err(TREEE_ERR_NOMEM, "hipMalloc bvh: %s", hipGetErrorString(e));
+	t->owner = ctx;
+	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->P * 2 * 2, &t->d_bvh));
 	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 4)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, t->d_bvh);
 	for (uint32_t lvl = t->P >> 1; lvl >= 1; lvl >>= 1) // nodes [lvl, 2*lvl)
 		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
@@ -992,9 +993,8 @@ int32_t treee_knn_build(const float *xyz, uint64_t n, treee_knn **out) {
 int32_t treee_knn_free(treee_knn *t) {
 	if (!t) return TREEE_OK;
 	(void)hipSetDevice(t->device);
-	(void)hipDeviceSynchronize();
 	t->sc.reset();
-	if (t->d_bvh) (void)hipFree(t->d_bvh);
+	pool_release(t->owner, t->d_bvh);
 	delete t;
 	return TREEE_OK;
 }

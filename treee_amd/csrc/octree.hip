@@ -19,6 +19,7 @@ struct treee_octree {
 	uint64_t n_lod = 0;
 	uint32_t leaf_cap = 256, lod_cap = 256;
 	int device = 0;
+	treee_ctx *owner = nullptr;
 };
 
 namespace {
@@ -138,11 +139,10 @@ int32_t grow_nodes(treee_ctx *ctx, treee_octree *o, uint64_t need) {
 	uint64_t cap = o->nodes_cap ? o->nodes_cap : 4096;
 	while (cap < need) cap *= 2;
 	treee_octree_node *p = nullptr;
-	TREEE_HIP(hipMalloc((void **)&p, cap * sizeof(treee_octree_node)));
+	TREEE_TRY(pool_alloc_t(ctx, cap, &p));
 	if (o->d_nodes) {
 		TREEE_HIP(hipMemcpyAsync(p, o->d_nodes, o->n_nodes * sizeof(treee_octree_node), hipMemcpyDeviceToDevice, ctx->stream));
-		TREEE_HIP(hipStreamSynchronize(ctx->stream));
-		(void)hipFree(o->d_nodes);
+		pool_release(ctx, o->d_nodes); // stream-ordered: the copy above is already enqueued
 	}
 	o->d_nodes = p;
 	o->nodes_cap = cap;
@@ -191,8 +191,8 @@ int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 	TREEE_HIP(hipMemcpyAsync(&lod_total, d_total, 4, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipStreamSynchronize(st));
 	o->n_lod = lod_total;
-	TREEE_HIP(hipMalloc((void **)&o->d_leaf, n * 4));
-	TREEE_HIP(hipMalloc((void **)&o->d_lod, (lod_total ? lod_total : 1) * 4ull));
+	TREEE_TRY(pool_alloc_t(ctx, n, &o->d_leaf));
+	TREEE_TRY(pool_alloc_t(ctx, (size_t)(lod_total ? lod_total : 1), &o->d_lod));
 	hipLaunchKernelGGL(k_oct_finish, dim3(div_up(nn, 4)), dim3(256), 0, st, o->d_nodes, nn, o->lod_cap, d_loff, o->d_leaf, o->d_lod);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
@@ -214,6 +214,7 @@ int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, con
 	TREEE_TRY(ctx->reset());
 	treee_octree *o = new treee_octree;
 	o->device = ctx->device;
+	o->owner = ctx;
 	o->leaf_cap = leaf_cap ? leaf_cap : 256;
 	o->lod_cap = lod_cap ? lod_cap : 256;
 	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, corner, size, o->sc.get());
@@ -243,11 +244,10 @@ int32_t treee_sort_build(const float *xyz, uint64_t n, const float corner[3], fl
 int32_t treee_octree_free(treee_octree *o) {
 	if (!o) return TREEE_OK;
 	(void)hipSetDevice(o->device);
-	(void)hipDeviceSynchronize();
 	o->sc.reset();
-	if (o->d_nodes) (void)hipFree(o->d_nodes);
-	if (o->d_leaf) (void)hipFree(o->d_leaf);
-	if (o->d_lod) (void)hipFree(o->d_lod);
+	pool_release(o->owner, o->d_nodes);
+	pool_release(o->owner, o->d_leaf);
+	pool_release(o->owner, o->d_lod);
 	delete o;
 	return TREEE_OK;
 }

@@ -358,13 +358,10 @@ int32_t gather_sorted_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_
 }
 
 void SortedCloud::release() {
-	if (d_keys || d_perm || d_sorted) {
-		(void)hipSetDevice(device);
-		(void)hipDeviceSynchronize();
-	}
-	if (d_keys) (void)hipFree(d_keys);
-	if (d_perm) (void)hipFree(d_perm);
-	if (d_sorted) (void)hipFree(d_sorted);
+	if (d_keys || d_perm || d_sorted) (void)hipSetDevice(device);
+	pool_release(owner, d_keys);
+	pool_release(owner, d_perm);
+	pool_release(owner, d_sorted);
 	d_keys = d_perm = nullptr;
 	d_sorted = nullptr;
 }
@@ -372,6 +369,7 @@ void SortedCloud::release() {
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc) {
 	sc->n = n;
 	sc->device = ctx->device;
+	sc->owner = ctx;
 	if (n >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per shard", (unsigned long long)n);
 	if (corner && size > 0.0f) {
 		for (int a = 0; a < 3; ++a) sc->corner[a] = corner[a];
@@ -380,9 +378,9 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 		TREEE_TRY(bbox_dev(ctx, d_xyz, n, sc->corner, &sc->size));
 	}
 	size_t cnt = n ? n : 1;
-	TREEE_HIP(hipMalloc((void **)&sc->d_keys, cnt * 4));
-	TREEE_HIP(hipMalloc((void **)&sc->d_perm, cnt * 4));
-	TREEE_HIP(hipMalloc((void **)&sc->d_sorted, cnt * 16));
+	TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_keys));
+	TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_perm));
+	TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_sorted));
 	uint32_t *d_keys_raw = nullptr;
 	TREEE_TRY(ctx->alloc_t(cnt, &d_keys_raw));
 	TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
