@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=15_000_000, help="points per GPU")
     ap.add_argument("--halo", type=float, default=2.0)
-    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="points of the CPU-baseline sample (about 10-30 s of oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -222,7 +222,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": measured_traffic(m_knn),
                 "algorithmic_bytes_per_point": BYTES["knn_curve"],
                 "points_per_launch": m_knn,
                 "kernel_ms": round(knn_ms, 3),
@@ -239,6 +239,18 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(points):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: FETCH_SIZE raw + WRITE_SIZE); only valid for the profiled size."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if t["points_per_launch"] == points:
+            return int(t["fetch_size_bytes_raw"] + t["write_size_bytes"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(sample):
     """The CPU oracle (port of the reference algorithms) on a forest patch of the same density,
     timed on this host: as-reference = 1 thread (calculations.rs:332 is a sequential iterator)."""
@@ -247,7 +259,8 @@ def cpu_baseline(sample):
 
     O.build()
     plot = PLOT * (sample / 15_000_000) ** 0.5
-    pts, seg = synth.forest_cloud(sample, plot=plot)
+    d_pts, d_seg = synth.forest_cloud_torch(sample, "cuda" if torch.cuda.is_available() else "cpu", plot=plot)
+    pts, seg = d_pts.cpu().numpy(), d_seg.cpu().numpy().astype(np.uint32)
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()
     mn = pts.min(0)
