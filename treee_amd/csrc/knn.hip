@@ -337,7 +337,10 @@ constexpr int SK = 32;          // list size (k <= 32 uses the first k)
 #define TREEE_KNN_WAVES 3
 #endif
 constexpr int SBUF = TREEE_SBUF;   // buffer slots per lane (power of two <= SK)
-constexpr int SCHUNK = SBUF / 2;   // candidates scanned between flush checks
+#ifndef TREEE_SCHUNK
+#define TREEE_SCHUNK (TREEE_SBUF / 4)
+#endif
+constexpr int SCHUNK = TREEE_SCHUNK; // candidates scanned between flush checks (flush when < SCHUNK slots are free)
 #ifndef TREEE_TRANSPOSE_BELOW
 #define TREEE_TRANSPOSE_BELOW 28
 #endif
@@ -410,8 +413,14 @@ __device__ __forceinline__ v4f issue_load_b128(const float4 *p) {
 	return r;
 }
 __device__ __forceinline__ void wait_load_b128(v4f &r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory"); }
-constexpr int LIST_CAP = 512;   // candidate buckets per wave; more -> packet-traversal fallback
-constexpr int FRONT_CAP = 1024; // BFS frontier (aliases the candidate buffer, which is empty then)
+#ifndef TREEE_LIST_CAP
+#define TREEE_LIST_CAP 512
+#endif
+constexpr int LIST_CAP = TREEE_LIST_CAP; // candidate buckets per wave; more -> packet-traversal fallback
+#ifndef TREEE_FRONT_CAP
+#define TREEE_FRONT_CAP (TREEE_SBUF * 64)
+#endif
+constexpr int FRONT_CAP = TREEE_FRONT_CAP; // BFS frontier; the default aliases the candidate buffer, which is empty then
 
 __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a) {
 	__shared__ __attribute__((aligned(16))) float tile[3][BUCKET]; // SoA candidate tile (x[], y[], z[])
@@ -456,7 +465,8 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 	const uint32_t wofs0 = (uint32_t)lane * 4u;
 	uint32_t wofs = wofs0;
 	constexpr uint32_t DB_OFS = SBUF * 64 * 4; // distance-bits plane behind the position plane
-	uint32_t st_buckets = 1, st_flush = 0, st_nodes = 0, st_need = 0, st_small = 0;
+	uint32_t st_buckets = 0, st_flush = 0, st_nodes = 0, st_need = 0, st_small = 0;
+	const unsigned long long st_t0 = a.stats ? __builtin_amdgcn_s_memtime() : 0ull;
 
 	auto flush = [&]() __attribute__((always_inline)) {
 		double B[SBUF];
@@ -490,10 +500,10 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 	};
 	// all 64 candidates of the staged tile against this lane's query; packed f32 math, two
 	// candidates per instruction; the append is branch-free (write always, count if it passes)
-	auto scan_tile = [&](uint32_t base, uint64_t lanes) __attribute__((always_inline)) {
+	auto scan_tile = [&](uint32_t base, uint64_t lanes, int first) __attribute__((always_inline)) {
 		const bool act = (lanes >> lane) & 1ull; // lanes outside `lanes` must not append (they saw this bucket already)
 #pragma unroll 1
-		for (int c0 = 0; c0 < BUCKET; c0 += SCHUNK) {
+		for (int c0 = first; c0 < BUCKET; c0 += SCHUNK) {
 			if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
 			uint32_t db[SCHUNK];
 #pragma unroll
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 	auto scan_bucket = [&](uint32_t b) __attribute__((always_inline)) {
 		if (b * BUCKET >= a.n) return;
 		stage(load_bucket(b));
-		scan_tile(b * BUCKET, ~0ull);
+		scan_tile(b * BUCKET, ~0ull, 0);
 	};
 	// lanes (queries) whose search ball still reaches the box
 	auto lane_box_hit = [&](float lox, float loy, float loz, float hix, float hiy, float hiz) __attribute__((always_inline)) -> uint64_t {
@@ -531,35 +541,86 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 	};
 
 	if (start >= a.nb) start = a.nb - 1;
-	scan_bucket(start);
+	// Own bucket, then its two neighbours in Morton order.  When a bucket straddles a jump of the
+	// curve, the lanes on its minority side find their real neighbours in the adjacent bucket; without
+	// it their threshold (and with it the wave's candidate list) would be enormous.
+#pragma unroll 1
+	for (int t = 0; t < 3; ++t) {
+		const uint32_t b = t == 0 ? start : (t == 1 ? start - 1u : start + 1u); // start-1 wraps to a huge value at 0
+		if (b >= a.nb) continue;
+		stage(load_bucket(b));
+		const uint32_t base = b * BUCKET;
+		int first = 0;
+		if (t == 0) {
+			// against an unbounded threshold everything passes, so the first 32 records go straight into
+			// the list (one 240-CE sort instead of eight buffer merges)
+#pragma unroll
+			for (int j = 0; j < SK; j += 2) {
+				const v2f cx = *(const v2f *)&tile[0][j];
+				const v2f cy = *(const v2f *)&tile[1][j];
+				const v2f cz = *(const v2f *)&tile[2][j];
+				const v2f dx = cx - qx2, dy = cy - qy2, dz = cz - qz2;
+				const v2f d = (dx * dx + dy * dy) + dz * dz;
+				const uint32_t d0 = __float_as_uint(d.x), d1 = __float_as_uint(d.y);
+				L[j] = d0 < a.maxbits ? key_make(d0, base + j) : key_make(a.maxbits, 0u); // strict `<` (best_set.rs:20-28)
+				L[j + 1] = d1 < a.maxbits ? key_make(d1, base + j + 1) : key_make(a.maxbits, 0u);
+			}
+			bitonic_sort<SK>(L);
+			thr = key_db(L[SK - 1]);
+			first = SK;
+		}
+		scan_tile(base, ~0ull, first);
+		st_buckets++;
+	}
 	if (__any(wofs != wofs0)) flush(); // threshold = 32nd best inside the own bucket
 
 	// ---- candidate buckets by a wave-parallel BFS: one lane per tree node -----------------------
 	// Query box of the wave and its largest threshold bound every lane's search ball, so a node
 	// whose box is farther than that from the query box cannot matter to any lane.  Seeds are the
 	// sibling subtrees along the path from the own bucket to the root (an exact cover).
-	float wlo[3], whi[3];
+	// Query boxes: one per group of 8 consecutive lanes (Morton-adjacent queries), each with the
+	// largest threshold of its lanes.  A single box for the whole wave is far too loose when the
+	// bucket straddles a jump of the Morton curve.  The boxes live in the (idle) tile memory.
+	constexpr int NG = 8;
+	float *gbox = &tile[0][0]; // [NG][8]: lo.xyz, tau bits, hi.xyz, pad
 	{
 		const float q[3] = {qx, qy, qz};
+		float glo[3], ghi[3];
 #pragma unroll
 		for (int c = 0; c < 3; ++c) {
 			float lo = live ? q[c] : INFINITY, hi = live ? q[c] : -INFINITY;
 #pragma unroll
-			for (int o = 32; o > 0; o >>= 1) {
+			for (int o = 4; o > 0; o >>= 1) {
 				lo = fminf(lo, __shfl_xor(lo, o, 64));
 				hi = fmaxf(hi, __shfl_xor(hi, o, 64));
 			}
-			wlo[c] = lo;
-			whi[c] = hi;
+			glo[c] = lo;
+			ghi[c] = hi;
+		}
+		uint32_t gtau = live ? thr : 0u;
+#pragma unroll
+		for (int o = 4; o > 0; o >>= 1) {
+			const uint32_t t = __shfl_xor(gtau, o, 64);
+			gtau = t > gtau ? t : gtau;
+		}
+		if ((lane & 7) == 0) {
+			float *g = gbox + (lane >> 3) * 8;
+			g[0] = glo[0];
+			g[1] = glo[1];
+			g[2] = glo[2];
+			g[3] = __uint_as_float(gtau);
+			g[4] = ghi[0];
+			g[5] = ghi[1];
+			g[6] = ghi[2];
+			g[7] = 0.0f;
 		}
 	}
-	uint32_t tau = live ? thr : 0u;
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		const uint32_t t = __shfl_xor(tau, o, 64);
-		tau = t > tau ? t : tau;
-	}
+#if TREEE_FRONT_CAP > TREEE_SBUF * 64
+	__shared__ uint32_t s_front[2 * FRONT_CAP];
+	uint32_t *front = s_front;
+#else
 	uint32_t *front = (uint32_t *)buf; // two frontiers of FRONT_CAP nodes alias the (empty) buffer
+#endif
 	uint32_t cur = 0, m = 0, list_m = 0;
 	for (uint32_t nd = a.P + start; nd > 1u; nd >>= 1) ++m; // tree depth = number of seeds (<= 31)
 	if ((uint32_t)lane < m) front[lane] = ((a.P + start) >> lane) ^ 1u;
@@ -573,12 +634,19 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 			const bool valid = idx < m;
 			const uint32_t node = valid ? front[cur * FRONT_CAP + idx] : 1u;
 			const float4 lo = a.bvh[2ull * node + 0], hi = a.bvh[2ull * node + 1];
-			const float dx = fmaxf(fmaxf(lo.x - whi[0], wlo[0] - hi.x), 0.0f);
-			const float dy = fmaxf(fmaxf(lo.y - whi[1], wlo[1] - hi.y), 0.0f);
-			const float dz = fmaxf(fmaxf(lo.z - whi[2], wlo[2] - hi.z), 0.0f);
-			const float bd = (dx * dx + dy * dy) + dz * dz;
-			const bool hit = valid && __float_as_uint(bd) <= tau;
-			const bool leafhit = hit && node >= a.P && (node - a.P) < a.nb;
+			bool hit = false;
+#pragma unroll
+			for (int g = 0; g < NG; ++g) { // same address in every lane: LDS broadcast
+				const float4 blo = *(const float4 *)(gbox + g * 8), bhi = *(const float4 *)(gbox + g * 8 + 4);
+				const float dx = fmaxf(fmaxf(lo.x - bhi.x, blo.x - hi.x), 0.0f);
+				const float dy = fmaxf(fmaxf(lo.y - bhi.y, blo.y - hi.y), 0.0f);
+				const float dz = fmaxf(fmaxf(lo.z - bhi.z, blo.z - hi.z), 0.0f);
+				const float bd = (dx * dx + dy * dy) + dz * dz;
+				hit = hit || (__float_as_uint(bd) <= __float_as_uint(blo.w));
+			}
+			hit = hit && valid;
+			// the own bucket's Morton neighbours were scanned above (the own bucket is no seed's descendant)
+			const bool leafhit = hit && node >= a.P && (node - a.P) < a.nb && node - a.P != start - 1u && node - a.P != start + 1u;
 			const bool innerhit = hit && node < a.P;
 			const uint64_t bl = __ballot(leafhit), bi = __ballot(innerhit);
 			if (leafhit) {
@@ -694,7 +762,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 				}
 				if (full) {
 					if (small) stage(cand); // deferred queries of a transposed bucket (rare)
-					scan_tile(leaf * BUCKET, full);
+					scan_tile(leaf * BUCKET, full, 0);
 				}
 				st_buckets++;
 			}
@@ -713,7 +781,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 					i = 2u * i;
 					continue;
 				}
-				if (hit) {
+				if (hit && i - a.P != start - 1u && i - a.P != start + 1u) { // the neighbours were scanned above
 					scan_bucket(i - a.P);
 					st_buckets++;
 				}
@@ -733,6 +801,11 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 		atomicAdd(&a.stats[3], 1u);
 		atomicAdd(&a.stats[4], st_need);
 		atomicAdd(&a.stats[5], st_small);
+		const uint32_t cyc = (uint32_t)((__builtin_amdgcn_s_memtime() - st_t0) >> 6); // 64-cycle units
+		atomicAdd(&a.stats[6], cyc >> 4);
+		atomicMax(&a.stats[7], cyc);
+		if (overflow) atomicAdd(&a.stats[8], 1u);
+		atomicAdd(&a.stats[9 + (cyc >> 10 > 21 ? 21 : cyc >> 10)], 1u); // histogram, 65536-cycle bins
 	}
 	if (!live) return;
 
@@ -867,8 +940,8 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	a.thr_seed = 0;
 	static const bool want_stats = getenv("TREEE_KNN_STATS") != nullptr; // diagnostic counters
 	if (want_stats) {
-		TREEE_TRY(ctx->alloc_t(8, &a.stats));
-		TREEE_HIP(hipMemsetAsync(a.stats, 0, 32, ctx->stream));
+		TREEE_TRY(ctx->alloc_t(32, &a.stats));
+		TREEE_HIP(hipMemsetAsync(a.stats, 0, 128, ctx->stream));
 	}
 	const uint32_t nwaves = div_up(nq, 64);
 	if (d_q) { // external queries: Morton-sort them so that a wave is spatially compact
@@ -895,9 +968,12 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	}
 	TREEE_LAUNCH_CHECK();
 	if (a.stats) {
-		uint32_t h[8];
-		TREEE_HIP(hipMemcpyAsync(h, a.stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+		uint32_t h[32];
+		TREEE_HIP(hipMemcpyAsync(h, a.stats, 128, hipMemcpyDeviceToHost, ctx->stream));
 		TREEE_HIP(hipStreamSynchronize(ctx->stream));
+		fprintf(stderr, "[treee knn cycles] mean=%.0f max=%.0f overflow-waves=%u hist(64k-cycle bins):", h[6] * 1024.0 / h[3], h[7] * 64.0, h[8]);
+		for (int i = 0; i < 22; ++i) fprintf(stderr, " %u", h[9 + i]);
+		fprintf(stderr, "\n");
 		fprintf(stderr, "[treee knn stats] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f need/bucket=%.2f small-buckets/wave=%.2f\n", h[3], h[0] / (double)h[3],
 		        h[1] / (double)h[3], h[2] / (double)h[3], h[4] / (double)(h[0] - h[3] ? h[0] - h[3] : 1), h[5] / (double)h[3]);
 		static const bool want_ideal = getenv("TREEE_KNN_IDEAL") != nullptr;
@@ -905,9 +981,9 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 			TREEE_TRY(ctx->alloc_t(nq, &a.thr_io));
 			hipLaunchKernelGGL(k_knn_sorted32, dim3(nwaves), dim3(64), 0, ctx->stream, a);
 			a.thr_seed = 1;
-			TREEE_HIP(hipMemsetAsync(a.stats, 0, 32, ctx->stream));
+			TREEE_HIP(hipMemsetAsync(a.stats, 0, 128, ctx->stream));
 			hipLaunchKernelGGL(k_knn_sorted32, dim3(nwaves), dim3(64), 0, ctx->stream, a);
-			TREEE_HIP(hipMemcpyAsync(h, a.stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+			TREEE_HIP(hipMemcpyAsync(h, a.stats, 128, hipMemcpyDeviceToHost, ctx->stream));
 			TREEE_HIP(hipStreamSynchronize(ctx->stream));
 			fprintf(stderr, "[treee knn IDEAL] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f\n", h[3], h[0] / (double)h[3], h[1] / (double)h[3], h[2] / (double)h[3]);
 		}
