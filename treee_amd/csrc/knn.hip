@@ -342,7 +342,7 @@ constexpr int SBUF = TREEE_SBUF;   // buffer slots per lane (power of two <= SK)
 #endif
 constexpr int SCHUNK = TREEE_SCHUNK; // candidates scanned between flush checks (flush when < SCHUNK slots are free)
 #ifndef TREEE_TRANSPOSE_BELOW
-#define TREEE_TRANSPOSE_BELOW 28
+#define TREEE_TRANSPOSE_BELOW 20
 #endif
 constexpr int TRANSPOSE_BELOW = TREEE_TRANSPOSE_BELOW; // buckets needed by fewer queries are scanned transposed
 // Keys are (distance bits + KEY_BIAS) << 32 | sorted position.  Distances are >= +0, so the
@@ -422,10 +422,18 @@ constexpr int LIST_CAP = TREEE_LIST_CAP; // candidate buckets per wave; more -> 
 #endif
 constexpr int FRONT_CAP = TREEE_FRONT_CAP; // BFS frontier; the default aliases the candidate buffer, which is empty then
 
-__global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a) {
+// DIAG = true compiles the diagnostic counters in (TREEE_KNN_STATS); the shipped instantiation has none
+#define ST(x)                  \
+	do {                       \
+		if constexpr (DIAG) {  \
+			x;                 \
+		}                      \
+	} while (0)
+template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a) {
 	__shared__ __attribute__((aligned(16))) float tile[3][BUCKET]; // SoA candidate tile (x[], y[], z[])
 	__shared__ uint32_t buf[2 * SBUF * 64]; // [pos | distance bits][slot][lane]: conflict-free per slot
 	__shared__ uint32_t s_list[LIST_CAP];
+	__shared__ __attribute__((aligned(16))) float4 s_gbox[64][2]; // boxes of the current group of listed buckets
 	const int lane = threadIdx.x;
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -459,14 +467,15 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 #pragma unroll
 	for (int i = 0; i < SK; ++i) L[i] = key_make(a.maxbits, 0u);
 	uint32_t thr = a.maxbits; // distance bits of the current 32nd best
-	if (a.thr_io && a.thr_seed && live) thr = a.thr_io[slot]; // diagnostic lower bound: start from the final answer
+	ST(if (a.thr_io && a.thr_seed && live) thr = a.thr_io[slot]); // diagnostic lower bound: start from the final answer
 	// byte offset of this lane's next free buffer slot (slot stride 256 B); the buffer is appended
 	// to without branches: every candidate is written, the offset only advances if it passed
 	const uint32_t wofs0 = (uint32_t)lane * 4u;
 	uint32_t wofs = wofs0;
 	constexpr uint32_t DB_OFS = SBUF * 64 * 4; // distance-bits plane behind the position plane
 	uint32_t st_buckets = 0, st_flush = 0, st_nodes = 0, st_need = 0, st_small = 0;
-	const unsigned long long st_t0 = a.stats ? __builtin_amdgcn_s_memtime() : 0ull;
+	unsigned long long st_t0 = 0ull;
+	ST(st_t0 = __builtin_amdgcn_s_memtime());
 
 	auto flush = [&]() __attribute__((always_inline)) {
 		double B[SBUF];
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 			const uint32_t nt = key_db(L[SK - 1]);
 			thr = nt < thr ? nt : thr;
 		}
-		st_flush++;
+		ST(st_flush++);
 		wofs = wofs0;
 	};
 
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 			first = SK;
 		}
 		scan_tile(base, ~0ull, first);
-		st_buckets++;
+		ST(st_buckets++);
 	}
 	if (__any(wofs != wofs0)) flush(); // threshold = 32nd best inside the own bucket
 
@@ -635,8 +644,8 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 			const uint32_t node = valid ? front[cur * FRONT_CAP + idx] : 1u;
 			const float4 lo = a.bvh[2ull * node + 0], hi = a.bvh[2ull * node + 1];
 			bool hit = false;
-#pragma unroll
-			for (int g = 0; g < NG; ++g) { // same address in every lane: LDS broadcast
+#pragma unroll 2
+			for (int g = 0; g < NG; ++g) { // same address in every lane: LDS broadcast (unroll 2: register pressure)
 				const float4 blo = *(const float4 *)(gbox + g * 8), bhi = *(const float4 *)(gbox + g * 8 + 4);
 				const float dx = fmaxf(fmaxf(lo.x - bhi.x, blo.x - hi.x), 0.0f);
 				const float dy = fmaxf(fmaxf(lo.y - bhi.y, blo.y - hi.y), 0.0f);
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 			}
 			list_m += __popcll(bl);
 			next_m += 2u * __popcll(bi);
-			st_nodes++;
+			ST(st_nodes++);
 		}
 		if (list_m > (uint32_t)LIST_CAP || next_m > (uint32_t)FRONT_CAP) {
 			overflow = true;
@@ -679,23 +688,19 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 		for (uint32_t g = 0; g < list_m; g += 64) {
 			const uint32_t gcount = (list_m - g) < 64u ? (list_m - g) : 64u;
 			const uint32_t my_leaf = (uint32_t)lane < gcount ? s_list[g + lane] : 0u;
-			float4 alo = make_float4(INFINITY, INFINITY, INFINITY, 0.0f), ahi = make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f);
+			// boxes of this group of listed buckets go to LDS (8 VGPRs less to carry through the scans)
 			if ((uint32_t)lane < gcount) {
-				alo = a.bvh[2ull * (a.P + my_leaf) + 0];
-				ahi = a.bvh[2ull * (a.P + my_leaf) + 1];
+				s_gbox[lane][0] = a.bvh[2ull * (a.P + my_leaf) + 0];
+				s_gbox[lane][1] = a.bvh[2ull * (a.P + my_leaf) + 1];
 			}
+			__syncthreads();
 			// next listed bucket (index >= from) that some lane still needs, judged with the current
 			// threshold (it only ever shrinks, so a stale decision is merely conservative)
 			uint64_t need = 0; // queries that need the bucket find_next returned
 			auto find_next = [&](uint32_t from) __attribute__((always_inline)) -> uint32_t {
 				for (uint32_t j = from; j < gcount; ++j) {
-					const float lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alo.x), j));
-					const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alo.y), j));
-					const float lz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alo.z), j));
-					const float hx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.x), j));
-					const float hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.y), j));
-					const float hz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ahi.z), j));
-					need = lane_box_hit(lx, ly, lz, hx, hy, hz);
+					const float4 lo = s_gbox[j][0], hi = s_gbox[j][1]; // same address in every lane: LDS broadcast
+					need = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
 					if (need) return j;
 				}
 				return gcount;
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 				wait_load_b128(pf); // only this bucket's load is outstanding here
 				const bool inr = leaf * BUCKET + lane < a.n;
 				const float4 cand = make_float4(inr ? pf.x : nanv, inr ? pf.y : nanv, inr ? pf.z : nanv, 0.0f); // this lane's record of bucket `leaf`
-				st_need += (uint32_t)__popcll(need_cur);
+				ST(st_need += (uint32_t)__popcll(need_cur));
 				const bool small = __popcll(need_cur) < TRANSPOSE_BELOW;
 				// order matters: consume this bucket's registers (LDS staging) BEFORE the next load is issued,
 				// otherwise the wait for `cand` also drains the prefetch and exposes its latency
@@ -727,7 +732,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 					// ---- transposed scan: few queries still need this bucket, so lanes = candidates (kept in
 					// registers, no LDS staging) and the loop runs over the needing queries only.  A query
 					// whose buffer lacks room is deferred to the lane-parallel scan below (rare).
-					st_small++;
+					ST(st_small++);
 					full = 0ull;
 					const uint32_t mypos = leaf * BUCKET + lane;
 					uint64_t todo = need_cur;
@@ -764,7 +769,7 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 					if (small) stage(cand); // deferred queries of a transposed bucket (rare)
 					scan_tile(leaf * BUCKET, full, 0);
 				}
-				st_buckets++;
+				ST(st_buckets++);
 			}
 		}
 	} else {
@@ -776,14 +781,14 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 			for (;;) {
 				const float4 lo = a.bvh[2ull * i + 0], hi = a.bvh[2ull * i + 1];
 				const bool hit = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) != 0;
-				st_nodes++;
+				ST(st_nodes++);
 				if (hit && i < a.P) {
 					i = 2u * i;
 					continue;
 				}
 				if (hit && i - a.P != start - 1u && i - a.P != start + 1u) { // the neighbours were scanned above
 					scan_bucket(i - a.P);
-					st_buckets++;
+					ST(st_buckets++);
 				}
 				while (i != root && (i & 1u)) i >>= 1;
 				if (i == root) break;
@@ -793,8 +798,8 @@ __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a)
 		}
 	}
 	if (__any(wofs != wofs0)) flush();
-	if (a.thr_io && !a.thr_seed && live) a.thr_io[slot] = thr;
-	if (a.stats && lane == 0) {
+	ST(if (a.thr_io && !a.thr_seed && live) a.thr_io[slot] = thr);
+	if (DIAG && a.stats && lane == 0) {
 		atomicAdd(&a.stats[0], st_buckets);
 		atomicAdd(&a.stats[1], st_flush);
 		atomicAdd(&a.stats[2], st_nodes);
@@ -960,7 +965,10 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	}
 	static const bool force_heap = getenv("TREEE_KNN_FORCE_HEAP") != nullptr; // A/B and test hook
 	if (k <= (uint32_t)SK && !force_heap) {
-		hipLaunchKernelGGL(k_knn_sorted32, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+		if (a.stats)
+			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+		else
+			hipLaunchKernelGGL(k_knn_sorted32<false>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
 	} else {
 		if (lds > 64 * 1024)
 			TREEE_HIP(hipFuncSetAttribute((const void *)k_knn_heap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -979,10 +987,10 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		static const bool want_ideal = getenv("TREEE_KNN_IDEAL") != nullptr;
 		if (want_ideal && k <= (uint32_t)SK && !d_q) { // lower bound: rerun with every threshold seeded by its final value
 			TREEE_TRY(ctx->alloc_t(nq, &a.thr_io));
-			hipLaunchKernelGGL(k_knn_sorted32, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
 			a.thr_seed = 1;
 			TREEE_HIP(hipMemsetAsync(a.stats, 0, 128, ctx->stream));
-			hipLaunchKernelGGL(k_knn_sorted32, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
 			TREEE_HIP(hipMemcpyAsync(h, a.stats, 128, hipMemcpyDeviceToHost, ctx->stream));
 			TREEE_HIP(hipStreamSynchronize(ctx->stream));
 			fprintf(stderr, "[treee knn IDEAL] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f\n", h[3], h[0] / (double)h[3], h[1] / (double)h[3], h[2] / (double)h[3]);
