@@ -404,15 +404,6 @@ template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// Software-pipelined bucket load.  hipcc sinks an ordinary prefetch load below the scan it is
-// meant to overlap (and cannot count loads across the loop back-edge), so the load is issued
-// from inline asm and waited for by hand; the "+v" operand ties every later use to the wait.
-__device__ __forceinline__ v4f issue_load_b128(const float4 *p) {
-	v4f r;
-	asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-	return r;
-}
-__device__ __forceinline__ void wait_load_b128(v4f &r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory"); }
 #ifndef TREEE_LIST_CAP
 #define TREEE_LIST_CAP 512
 #endif
@@ -461,6 +452,9 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 	}
 	// dead lanes never pass the filter: NaN query -> NaN distance
 	if (!live) qx = __uint_as_float(0x7FC00000u);
+	// detach the scalars from the 16-byte record tuple they were loaded in: otherwise the register
+	// allocator spills the whole tuple and re-reads qx from scratch inside the hottest loops
+	asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(row));
 	const v2f qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 
 	double L[SK]; // FixedSet::new (best_set.rs:20-28): (max_distance, invalid)
@@ -712,12 +706,20 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 				return a.pts + (i < a.n ? i : a.n - 1u);
 			};
 			uint32_t j = find_next(0);
-			v4f pf = {nanv, nanv, nanv, 0.0f};
-			if (j < gcount) pf = issue_load_b128(bucket_ptr(j));
+			// Prefetch of the next bucket's record.  A plain load would be sunk by hipcc to its first use
+			// (below the scan it should overlap); a wavefront-scope release fence costs no instruction
+			// but pins the load above it.  The value stays an ordinary compiler-tracked register value:
+			// the compiler places the vmcnt wait at the use (an earlier version issued the load from inline
+			// asm and waited by hand, which faults as soon as the allocator copies the in-flight registers).
+			float4 pf = make_float4(nanv, nanv, nanv, 0.0f);
+			auto issue_prefetch = [&](uint32_t jj) __attribute__((always_inline)) {
+				pf = *bucket_ptr(jj);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			};
+			if (j < gcount) issue_prefetch(j);
 			while (j < gcount) {
 				const uint32_t leaf = (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, j);
 				const uint64_t need_cur = need;
-				wait_load_b128(pf); // only this bucket's load is outstanding here
 				const bool inr = leaf * BUCKET + lane < a.n;
 				const float4 cand = make_float4(inr ? pf.x : nanv, inr ? pf.y : nanv, inr ? pf.z : nanv, 0.0f); // this lane's record of bucket `leaf`
 				ST(st_need += (uint32_t)__popcll(need_cur));
@@ -726,7 +728,7 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 				// otherwise the wait for `cand` also drains the prefetch and exposes its latency
 				if (!small) stage(cand);
 				j = find_next(j + 1);
-				if (j < gcount) pf = issue_load_b128(bucket_ptr(j)); // in flight during the scan below
+				if (j < gcount) issue_prefetch(j); // in flight during the scan below
 				uint64_t full = ~0ull; // queries to serve with the lane-parallel scan
 				if (small) {
 					// ---- transposed scan: few queries still need this bucket, so lanes = candidates (kept in
