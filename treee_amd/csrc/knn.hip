@@ -468,10 +468,13 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 	uint32_t wofs = wofs0;
 	constexpr uint32_t DB_OFS = SBUF * 64 * 4; // distance-bits plane behind the position plane
 	uint32_t st_buckets = 0, st_flush = 0, st_nodes = 0, st_need = 0, st_small = 0;
-	unsigned long long st_t0 = 0ull;
-	ST(st_t0 = __builtin_amdgcn_s_memtime());
+	unsigned long long st_t0 = 0ull, st_tp = 0ull, st_tf = 0ull;
+	uint32_t st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	ST(st_t0 = st_tp = __builtin_amdgcn_s_memtime());
+#define PH(i) ST(const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st_ph[i] += (uint32_t)(t__ - st_tp); st_tp = t__)
 
 	auto flush = [&]() __attribute__((always_inline)) {
+		ST(st_tf = __builtin_amdgcn_s_memtime());
 		double B[SBUF];
 #pragma unroll
 		for (int s = 0; s < SBUF; ++s) {
@@ -488,6 +491,7 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 		}
 		ST(st_flush++);
 		wofs = wofs0;
+		ST(st_ph[6] += (uint32_t)(__builtin_amdgcn_s_memtime() - st_tf));
 	};
 
 	const float nanv = __uint_as_float(0x7FC00000u);
@@ -576,6 +580,7 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 		ST(st_buckets++);
 	}
 	if (__any(wofs != wofs0)) flush(); // threshold = 32nd best inside the own bucket
+	PH(0);
 
 	// ---- candidate buckets by a wave-parallel BFS: one lane per tree node -----------------------
 	// Query box of the wave and its largest threshold bound every lane's search ball, so a node
@@ -677,6 +682,8 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 	}
 	__syncthreads();
 
+	PH(1);
+	ST(st_ph[7] = list_m);
 	if (!overflow) {
 		// ---- scan the listed buckets; the next bucket's load is in flight during each scan -------
 		for (uint32_t g = 0; g < list_m; g += 64) {
@@ -705,7 +712,9 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 				const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, jj) * BUCKET + lane;
 				return a.pts + (i < a.n ? i : a.n - 1u);
 			};
+			PH(5);
 			uint32_t j = find_next(0);
+			PH(2);
 			// Prefetch of the next bucket's record.  A plain load would be sunk by hipcc to its first use
 			// (below the scan it should overlap); a wavefront-scope release fence costs no instruction
 			// but pins the load above it.  The value stays an ordinary compiler-tracked register value:
@@ -727,8 +736,10 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 				// order matters: consume this bucket's registers (LDS staging) BEFORE the next load is issued,
 				// otherwise the wait for `cand` also drains the prefetch and exposes its latency
 				if (!small) stage(cand);
+				PH(5);
 				j = find_next(j + 1);
 				if (j < gcount) issue_prefetch(j); // in flight during the scan below
+				PH(2);
 				uint64_t full = ~0ull; // queries to serve with the lane-parallel scan
 				if (small) {
 					// ---- transposed scan: few queries still need this bucket, so lanes = candidates (kept in
@@ -767,10 +778,12 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 						wofs = lane == q ? w + npass * 256u : wofs;
 					}
 				}
+				PH(3);
 				if (full) {
 					if (small) stage(cand); // deferred queries of a transposed bucket (rare)
 					scan_tile(leaf * BUCKET, full, 0);
 				}
+				PH(4);
 				ST(st_buckets++);
 			}
 		}
@@ -812,10 +825,14 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 		atomicAdd(&a.stats[6], cyc >> 4);
 		atomicMax(&a.stats[7], cyc);
 		if (overflow) atomicAdd(&a.stats[8], 1u);
+		for (int i = 0; i < 7; ++i) atomicAdd(&a.stats[40 + i], st_ph[i] >> 10);
+		atomicAdd(&a.stats[47], st_ph[7]);
+		atomicMax(&a.stats[48], st_ph[7]);
 		atomicAdd(&a.stats[9 + (cyc >> 10 > 21 ? 21 : cyc >> 10)], 1u); // histogram, 65536-cycle bins
 	}
 	if (!live) return;
 
+	PH(5);
 	const uint32_t k = a.k;
 	uint32_t count = 0;
 #pragma unroll
@@ -947,8 +964,8 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	a.thr_seed = 0;
 	static const bool want_stats = getenv("TREEE_KNN_STATS") != nullptr; // diagnostic counters
 	if (want_stats) {
-		TREEE_TRY(ctx->alloc_t(32, &a.stats));
-		TREEE_HIP(hipMemsetAsync(a.stats, 0, 128, ctx->stream));
+		TREEE_TRY(ctx->alloc_t(64, &a.stats));
+		TREEE_HIP(hipMemsetAsync(a.stats, 0, 256, ctx->stream));
 	}
 	const uint32_t nwaves = div_up(nq, 64);
 	if (d_q) { // external queries: Morton-sort them so that a wave is spatially compact
@@ -978,9 +995,11 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	}
 	TREEE_LAUNCH_CHECK();
 	if (a.stats) {
-		uint32_t h[32];
-		TREEE_HIP(hipMemcpyAsync(h, a.stats, 128, hipMemcpyDeviceToHost, ctx->stream));
+		uint32_t h[64];
+		TREEE_HIP(hipMemcpyAsync(h, a.stats, 256, hipMemcpyDeviceToHost, ctx->stream));
 		TREEE_HIP(hipStreamSynchronize(ctx->stream));
+		fprintf(stderr, "[treee knn phases] kcycles/wave: own+nbr=%.0f bfs=%.0f find_next=%.0f transposed=%.0f fullscan=%.0f other=%.0f | of which flushes=%.0f | listed buckets mean=%.1f max=%u\n", h[40] * 1.024 / h[3],
+		        h[41] * 1.024 / h[3], h[42] * 1.024 / h[3], h[43] * 1.024 / h[3], h[44] * 1.024 / h[3], h[45] * 1.024 / h[3], h[46] * 1.024 / h[3], h[47] / (double)h[3], h[48]);
 		fprintf(stderr, "[treee knn cycles] mean=%.0f max=%.0f overflow-waves=%u hist(64k-cycle bins):", h[6] * 1024.0 / h[3], h[7] * 64.0, h[8]);
 		for (int i = 0; i < 22; ++i) fprintf(stderr, " %u", h[9 + i]);
 		fprintf(stderr, "\n");
@@ -991,9 +1010,9 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 			TREEE_TRY(ctx->alloc_t(nq, &a.thr_io));
 			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
 			a.thr_seed = 1;
-			TREEE_HIP(hipMemsetAsync(a.stats, 0, 128, ctx->stream));
+			TREEE_HIP(hipMemsetAsync(a.stats, 0, 256, ctx->stream));
 			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
-			TREEE_HIP(hipMemcpyAsync(h, a.stats, 128, hipMemcpyDeviceToHost, ctx->stream));
+			TREEE_HIP(hipMemcpyAsync(h, a.stats, 256, hipMemcpyDeviceToHost, ctx->stream));
 			TREEE_HIP(hipStreamSynchronize(ctx->stream));
 			fprintf(stderr, "[treee knn IDEAL] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f\n", h[3], h[0] / (double)h[3], h[1] / (double)h[3], h[2] / (double)h[3]);
 		}

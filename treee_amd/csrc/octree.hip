@@ -39,11 +39,18 @@ __device__ __forceinline__ uint32_t lower_bound_prefix(const uint32_t *__restric
 }
 
 // 8 lanes per parent node of the current level; lane c finds the start of octant c.
+// lvl[0] = index of the level's first node, lvl[1] = number of nodes of the level (device memory:
+// the whole top-down build is enqueued without a host round trip per level)
 __global__ __launch_bounds__(256) void k_oct_split(const uint32_t *__restrict__ keys, treee_octree_node *__restrict__ nodes,
-                                                    uint32_t lvl_begin, uint32_t lvl_count, uint32_t leaf_cap,
+                                                    const uint32_t *__restrict__ lvl, uint32_t lvl_cap, uint32_t leaf_cap,
                                                     uint32_t *__restrict__ child_cnt, uint32_t *__restrict__ bounds) {
+	const uint32_t lvl_begin = lvl[0], lvl_count = lvl[1];
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	const uint32_t p = t >> 3, c = t & 7u;
+	if ((blockIdx.x * 256u >> 3) >= lvl_count) { // whole block past the level: only zero the scan input
+		if (p < lvl_cap && c == 0) child_cnt[p] = 0u;
+		return;
+	}
 	const bool live = p < lvl_count;
 	treee_octree_node nd;
 	nd.count = 0;
@@ -68,12 +75,20 @@ __global__ __launch_bounds__(256) void k_oct_split(const uint32_t *__restrict__ 
 			child_cnt[p] = __popc(mask);
 			nodes[lvl_begin + p].child_mask = mask;
 		}
+	} else if (p < lvl_cap && c == 0) {
+		child_cnt[p] = 0u;
 	}
 }
 
-__global__ __launch_bounds__(256) void k_oct_emit(treee_octree_node *__restrict__ nodes, uint32_t lvl_begin, uint32_t lvl_count,
-                                                   const uint32_t *__restrict__ child_off, const uint32_t *__restrict__ bounds) {
+__global__ __launch_bounds__(256) void k_oct_emit(treee_octree_node *__restrict__ nodes, uint32_t *__restrict__ lvl,
+                                                   const uint32_t *__restrict__ child_off, const uint32_t *__restrict__ bounds,
+                                                   const uint32_t *__restrict__ total) {
+	const uint32_t lvl_begin = lvl[0], lvl_count = lvl[1];
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t == 0) { // descriptor of the next level
+		lvl[2] = lvl_begin + lvl_count;
+		lvl[3] = *total;
+	}
 	const uint32_t p = t >> 3, c = t & 7u;
 	if (p >= lvl_count) return;
 	const treee_octree_node nd = nodes[lvl_begin + p];
@@ -95,7 +110,9 @@ __global__ __launch_bounds__(256) void k_oct_emit(treee_octree_node *__restrict_
 	nodes[first_child + __popc(nd.child_mask & ((1u << c) - 1u))] = ch;
 }
 
-__global__ void k_oct_root(treee_octree_node *nodes, uint32_t n) {
+__global__ void k_oct_root(treee_octree_node *nodes, uint32_t n, uint32_t *lvl) {
+	lvl[0] = 0;
+	lvl[1] = 1;
 	treee_octree_node r;
 	r.key_prefix = 0;
 	r.level = 0;
@@ -108,10 +125,15 @@ __global__ void k_oct_root(treee_octree_node *nodes, uint32_t n) {
 	nodes[0] = r;
 }
 
-__global__ __launch_bounds__(256) void k_oct_lod_count(const treee_octree_node *__restrict__ nodes, uint32_t n_nodes,
-                                                        uint32_t lod_cap, uint32_t *__restrict__ cnt) {
+__global__ __launch_bounds__(256) void k_oct_lod_count(const treee_octree_node *__restrict__ nodes, const uint32_t *__restrict__ lvl_last,
+                                                        uint32_t nodes_cap, uint32_t lod_cap, uint32_t *__restrict__ cnt) {
+	const uint32_t n_nodes = lvl_last[0] + lvl_last[1];
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n_nodes) return;
+	if (i >= nodes_cap) return;
+	if (i >= n_nodes) {
+		cnt[i] = 0u;
+		return;
+	}
 	const treee_octree_node nd = nodes[i];
 	cnt[i] = nd.first_child == NONE32 ? 0u : (nd.count < lod_cap ? nd.count : lod_cap);
 }
@@ -134,63 +156,54 @@ __global__ __launch_bounds__(256) void k_oct_finish(treee_octree_node *__restric
 	}
 }
 
-int32_t grow_nodes(treee_ctx *ctx, treee_octree *o, uint64_t need) {
-	if (need <= o->nodes_cap) return TREEE_OK;
-	uint64_t cap = o->nodes_cap ? o->nodes_cap : 4096;
-	while (cap < need) cap *= 2;
-	treee_octree_node *p = nullptr;
-	TREEE_TRY(pool_alloc_t(ctx, cap, &p));
-	if (o->d_nodes) {
-		TREEE_HIP(hipMemcpyAsync(p, o->d_nodes, o->n_nodes * sizeof(treee_octree_node), hipMemcpyDeviceToDevice, ctx->stream));
-		pool_release(ctx, o->d_nodes); // stream-ordered: the copy above is already enqueued
-	}
-	o->d_nodes = p;
-	o->nodes_cap = cap;
-	return TREEE_OK;
-}
-
 int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 	const uint64_t n = o->sc->n;
 	if (n == 0) return TREEE_OK;
 	hipStream_t st = ctx->stream;
-	TREEE_TRY(grow_nodes(ctx, o, 4096));
-	hipLaunchKernelGGL(k_oct_root, dim3(1), dim3(1), 0, st, o->d_nodes, (uint32_t)n);
-	o->n_nodes = 1;
-	uint32_t lvl_begin = 0, lvl_count = 1;
-	uint32_t *d_total = nullptr;
-	TREEE_TRY(ctx->alloc_t(1, &d_total));
-	for (uint32_t level = 0; level < DEPTH && lvl_count > 0; ++level) {
-		uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_bounds = nullptr;
-		TREEE_TRY(ctx->alloc_t(lvl_count, &d_cnt));
-		TREEE_TRY(ctx->alloc_t(lvl_count, &d_off));
-		TREEE_TRY(ctx->alloc_t((size_t)lvl_count * 8, &d_bounds));
-		const uint32_t grid = div_up((uint64_t)lvl_count * 8, 256);
-		hipLaunchKernelGGL(k_oct_split, dim3(grid), dim3(256), 0, st, o->sc->d_keys, o->d_nodes, lvl_begin, lvl_count, o->leaf_cap, d_cnt, d_bounds);
-		TREEE_LAUNCH_CHECK();
-		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_cnt, d_off, lvl_count, d_total));
-		uint32_t total = 0;
-		TREEE_HIP(hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, st));
-		TREEE_HIP(hipStreamSynchronize(st));
-		if (total == 0) break;
-		TREEE_TRY(grow_nodes(ctx, o, o->n_nodes + total));
-		hipLaunchKernelGGL(k_oct_emit, dim3(grid), dim3(256), 0, st, o->d_nodes, lvl_begin, lvl_count, d_off, d_bounds);
-		TREEE_LAUNCH_CHECK();
-		lvl_begin += lvl_count;
-		lvl_count = total;
-		o->n_nodes += total;
+	// Capacity per level: a node is split only if it holds more than leaf_cap points, so a level has at
+	// most n/(leaf_cap+1) split nodes and the next one at most 8x that many nodes (and never more than
+	// 8^level).  With these bounds every level can be enqueued without knowing the previous count.
+	const uint64_t per_level = 8ull * (n / ((uint64_t)o->leaf_cap + 1ull)) + 8ull;
+	uint32_t lvl_cap[DEPTH + 1];
+	uint64_t nodes_cap = 0, pow8 = 1;
+	for (uint32_t l = 0; l <= DEPTH; ++l) {
+		lvl_cap[l] = (uint32_t)(pow8 < per_level ? pow8 : per_level);
+		nodes_cap += lvl_cap[l];
+		if (pow8 < (1ull << 40)) pow8 *= 8ull;
 	}
-	// LOD offsets + per-point leaf ids
-	const uint32_t nn = (uint32_t)o->n_nodes;
+	TREEE_TRY(pool_alloc_t(ctx, nodes_cap, &o->d_nodes));
+	o->nodes_cap = nodes_cap;
+	uint32_t *d_lvl = nullptr, *d_total = nullptr;
+	TREEE_TRY(ctx->alloc_t(2 * (DEPTH + 2), &d_lvl));
+	TREEE_TRY(ctx->alloc_t(2, &d_total));
+	hipLaunchKernelGGL(k_oct_root, dim3(1), dim3(1), 0, st, o->d_nodes, (uint32_t)n, d_lvl);
+	for (uint32_t level = 0; level < DEPTH; ++level) {
+		const uint32_t cap = lvl_cap[level];
+		uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_bounds = nullptr;
+		TREEE_TRY(ctx->alloc_t(cap, &d_cnt));
+		TREEE_TRY(ctx->alloc_t(cap, &d_off));
+		TREEE_TRY(ctx->alloc_t((size_t)cap * 8, &d_bounds));
+		const uint32_t grid = div_up((uint64_t)cap * 8, 256);
+		hipLaunchKernelGGL(k_oct_split, dim3(grid), dim3(256), 0, st, o->sc->d_keys, o->d_nodes, d_lvl + 2 * level, cap, o->leaf_cap, d_cnt, d_bounds);
+		TREEE_LAUNCH_CHECK();
+		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_cnt, d_off, cap, d_total));
+		hipLaunchKernelGGL(k_oct_emit, dim3(grid), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * level, d_off, d_bounds, d_total);
+		TREEE_LAUNCH_CHECK();
+	}
+	// LOD offsets, then the only host round trip of the build: node count + LOD total
 	uint32_t *d_lcnt = nullptr, *d_loff = nullptr;
-	TREEE_TRY(ctx->alloc_t(nn, &d_lcnt));
-	TREEE_TRY(ctx->alloc_t(nn, &d_loff));
-	hipLaunchKernelGGL(k_oct_lod_count, dim3(div_up(nn, 256)), dim3(256), 0, st, o->d_nodes, nn, o->lod_cap, d_lcnt);
+	TREEE_TRY(ctx->alloc_t(nodes_cap, &d_lcnt));
+	TREEE_TRY(ctx->alloc_t(nodes_cap, &d_loff));
+	hipLaunchKernelGGL(k_oct_lod_count, dim3(div_up(nodes_cap, 256)), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * DEPTH, (uint32_t)nodes_cap, o->lod_cap, d_lcnt);
 	TREEE_LAUNCH_CHECK();
-	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_lcnt, d_loff, nn, d_total));
-	uint32_t lod_total = 0;
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_lcnt, d_loff, nodes_cap, d_total));
+	uint32_t h_last[2] = {0, 0}, lod_total = 0;
+	TREEE_HIP(hipMemcpyAsync(h_last, d_lvl + 2 * DEPTH, 8, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipMemcpyAsync(&lod_total, d_total, 4, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipStreamSynchronize(st));
+	o->n_nodes = (uint64_t)h_last[0] + h_last[1];
 	o->n_lod = lod_total;
+	const uint32_t nn = (uint32_t)o->n_nodes;
 	TREEE_TRY(pool_alloc_t(ctx, n, &o->d_leaf));
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)(lod_total ? lod_total : 1), &o->d_lod));
 	hipLaunchKernelGGL(k_oct_finish, dim3(div_up(nn, 4)), dim3(256), 0, st, o->d_nodes, nn, o->lod_cap, d_loff, o->d_leaf, o->d_lod);
