@@ -335,3 +335,80 @@ def test_full_size_15m_properties(T, oracle):
     g_ent, g_cnt = sub.k_nearest_batch(pts[:20_000], 31, F32_MAX)
     r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts[:20_000], 31, F32_MAX, threads=8)
     check_knn_contract(pts, pts[:20_000], g_ent, g_cnt, r_ent, r_cnt)
+
+
+# ---------------------------------------------------------------- kNN edge cases (sorted-32 kernel paths)
+@pytest.mark.parametrize("k", [1, 2, 7, 16, 31, 32, 33])
+def test_knn_every_small_k(T, oracle, k):
+    pts = quantised_cloud(6000, 300 + k, extent=(12, 4, 12))
+    r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts[:1500], k, F32_MAX)
+    g_ent, g_cnt = T.KDTree.new(pts).k_nearest_batch(pts[:1500], k, F32_MAX)
+    check_knn_contract(pts, pts[:1500], g_ent, g_cnt, r_ent, r_cnt)
+
+
+def test_knn_massive_duplicates_and_ties(T, oracle):
+    # 3000 copies of one point + a sparse shell: every threshold ties, buffers overflow, lists are long
+    rng = np.random.default_rng(12)
+    pts = np.concatenate([np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (3000, 1)),
+                          (rng.random((2000, 3)) * 50).astype(np.float32),
+                          np.tile(np.array([[40.0, 2.0, 3.0]], np.float32), (70, 1))])
+    q = np.concatenate([pts[:40], pts[3000:3200], pts[-20:], np.array([[1.0, 2.0, 3.5], [1000.0, -500.0, 3.0]], np.float32)])
+    for maxd in (F32_MAX, 0.25, 1e-12):
+        r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(q, 31, maxd)
+        g_ent, g_cnt = T.KDTree.new(pts).k_nearest_batch(q, 31, maxd)
+        check_knn_contract(pts, q, g_ent, g_cnt, r_ent, r_cnt)
+
+
+def test_knn_nan_inf_and_extreme_inputs(T, oracle):
+    rng = np.random.default_rng(21)
+    pts = (rng.random((5000, 3)) * 20).astype(np.float32)
+    pts[10] = [np.nan, 1, 1]
+    pts[11] = [1, np.inf, 1]
+    pts[12] = [1e30, 1e30, -1e30]
+    pts[13] = [-3e38, 0, 0]
+    q = np.concatenate([pts[:64], np.array([[np.nan, 0, 0], [np.inf, 0, 0], [5, 5, 5], [1e30, 1e30, -1e30], [-1e5, 7, 3e4]], np.float32)])
+    for maxd in (F32_MAX, float("inf"), 4.0):
+        r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(q, 31, maxd)
+        g_ent, g_cnt = T.KDTree.new(pts).k_nearest_batch(q, 31, maxd)
+        check_knn_contract(pts, q, g_ent, g_cnt, r_ent, r_cnt)
+    # degenerate radii: NaN / zero / negative -> nothing is < max_distance
+    tree = T.KDTree.new(pts)
+    for maxd in (float("nan"), 0.0, -1.0):
+        g_ent, g_cnt = tree.k_nearest_batch(q[:20], 5, maxd)
+        assert np.all(g_cnt == 0) and np.all(g_ent["index"] == T.INVALID_INDEX)
+
+
+def test_knn_far_and_scattered_external_queries(T, oracle):
+    # queries nowhere near the cloud and in random order: incoherent waves, huge radii, fallback traversal
+    pts = quantised_cloud(40_000, 99, extent=(60, 8, 60))
+    rng = np.random.default_rng(4)
+    q = np.concatenate([(rng.random((500, 3)) * np.array([600, 80, 600]) - np.array([270, 36, 270])).astype(np.float32), pts[rng.integers(0, len(pts), 500)]])
+    rng.shuffle(q)
+    r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(q, 31, F32_MAX, threads=8)
+    g_ent, g_cnt = T.KDTree.new(pts).k_nearest_batch(q, 31, F32_MAX)
+    check_knn_contract(pts, q, g_ent, g_cnt, r_ent, r_cnt)
+    r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(q, 20, 9.0, threads=8)
+    g_ent, g_cnt = T.KDTree.new(pts).k_nearest_batch(q, 20, 9.0)
+    check_knn_contract(pts, q, g_ent, g_cnt, r_ent, r_cnt)
+
+
+def test_knn_heap_and_sorted_kernels_agree(T):
+    import os
+    import subprocess
+    import sys
+
+    # the general-k heap kernel (forced through the env hook in a child process) must give the
+    # same bits as the sorted-32 kernel: both implement the total order (distance, morton key, index)
+    code = ("import numpy as np, treee_amd as T\n"
+            "rng=np.random.default_rng(3); p=(np.round(rng.random((20000,3))*np.array([30,8,30])*100)/100).astype(np.float32)\n"
+            "e,c=T.KDTree.new(p).k_nearest_batch(p[:4000],31,float(np.finfo(np.float32).max))\n"
+            "import hashlib; print(hashlib.sha256(e.tobytes()+c.tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for force in (False, True):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("TREEE_KNN_FORCE_HEAP", None)
+        if force:
+            env["TREEE_KNN_FORCE_HEAP"] = "1"
+        out.append(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip().splitlines()[-1])
+    assert out[0] == out[1]
