@@ -412,3 +412,45 @@ def test_knn_heap_and_sorted_kernels_agree(T):
             env["TREEE_KNN_FORCE_HEAP"] = "1"
         out.append(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip().splitlines()[-1])
     assert out[0] == out[1]
+
+
+def test_full_size_150m_properties(T):
+    """BASELINE.json configs[3] size (150 M points, 632 m plot) on ONE GPU: size-independent
+    properties of sort/octree, and sampled exact kNN checks against a torch brute force."""
+    import torch
+
+    from treee_amd import synth
+
+    n = 150_000_000
+    d_pts, _ = synth.forest_cloud_torch(n, "cuda", plot=632.0, seed=synth.SEED_FOREST_150M)
+    oc = T.Octree(d_pts)
+    keys = torch.from_numpy(oc.array("keys").view(np.int32)).cuda()
+    assert bool((keys[1:] >= keys[:-1]).all())  # 30-bit keys: the signed view orders like the unsigned one
+    perm = torch.from_numpy(oc.array("perm").view(np.int32)).cuda().long()
+    seen = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    seen[perm] = 1
+    assert int(seen.sum()) == n  # a permutation
+    del seen, keys
+    nodes = oc.array("nodes")
+    leaves = nodes[nodes["first_child"] == 0xFFFFFFFF]
+    assert int(leaves["count"].astype(np.int64).sum()) == n and int(nodes["count"][0]) == n
+    tree = T.KDTree.from_octree(oc)
+    curve = tree.curvature_dev(31)
+    torch.cuda.synchronize()
+    ok = ~torch.isnan(curve)
+    assert float(ok.float().mean()) > 0.999 and float(curve[ok].min()) > -1e-3 and float(curve[ok].max()) < 1.001
+    sample = torch.randint(0, n, (4096,), generator=torch.Generator().manual_seed(7)).cuda()
+    dist, index, counts = tree.k_nearest_dev(d_pts[sample], 31)
+    assert int(counts.min()) == 31 and bool((dist[:, 0] == 0).all()) and bool((dist[:, 1:] >= dist[:, :-1]).all())
+    for r in range(0, 4096, 256):  # 16 queries against all 150 M points, reference op order
+        q = d_pts[sample[r]]
+        dx, dy, dz = d_pts[:, 0] - q[0], d_pts[:, 1] - q[1], d_pts[:, 2] - q[2]
+        d = (dx * dx + dy * dy) + dz * dz
+        ref = torch.sort(torch.topk(d, 31, largest=False).values).values
+        assert torch.equal(ref, dist[r]), r
+        got = d_pts[index[r].long()]  # the returned indices really are at those distances
+        gx, gy, gz = got[:, 0] - q[0], got[:, 1] - q[1], got[:, 2] - q[2]
+        assert torch.equal((gx * gx + gy * gy) + gz * gz, dist[r])
+        del d, dx, dy, dz
+    tree.close()
+    oc.close()
