@@ -454,3 +454,30 @@ def test_full_size_150m_properties(T):
         del d, dx, dy, dz
     tree.close()
     oc.close()
+
+
+def test_host_api_is_thread_safe(T, oracle):
+    """k-nearest trees are Sync in the reference (queries take &self); the host-pointer C ABI shares one
+    default context, so concurrent callers are serialised inside the library and must all get right answers."""
+    import threading
+
+    pts = quantised_cloud(20_000, 5, extent=(20, 6, 20))
+    tree = T.KDTree.new(pts)
+    r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts[:4000], 31, F32_MAX, threads=4)
+    errors = []
+
+    def worker(lo, hi):
+        try:
+            for _ in range(3):
+                g_ent, g_cnt = tree.k_nearest_batch(pts[lo:hi], 31, F32_MAX)
+                check_knn_contract(pts, pts[lo:hi], g_ent, g_cnt, r_ent[lo:hi], r_cnt[lo:hi])
+                T.curvature(pts[lo:hi + 100])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i * 1000, (i + 1) * 1000)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

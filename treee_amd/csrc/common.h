@@ -159,6 +159,12 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 
 // default context for the host-pointer API (created lazily, one per process)
 int32_t default_ctx(treee_ctx **out);
+// The host-pointer API shares that context (one stream, one workspace): calls from several host threads
+// are serialised by this recursive lock (host entry points call each other).
+std::recursive_mutex &default_ctx_mutex();
+#define TREEE_DEFAULT_CTX(ctx)                                                     \
+	std::lock_guard<std::recursive_mutex> default_ctx_lock__(default_ctx_mutex()); \
+	TREEE_TRY(default_ctx(&ctx))
 
 template <class T> struct DevBuf { // RAII for hipMalloc'd temporaries in host wrappers
 	T *p = nullptr;

@@ -83,6 +83,10 @@ void pool_release(treee_ctx *ctx, void *p) {
 }
 
 static std::mutex g_default_mu;
+std::recursive_mutex &default_ctx_mutex() {
+	static std::recursive_mutex m;
+	return m;
+}
 static treee_ctx *g_default = nullptr;
 
 int32_t default_ctx(treee_ctx **out) {

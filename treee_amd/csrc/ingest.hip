@@ -121,7 +121,7 @@ int32_t treee_decode_las_records(const uint8_t *rec, uint64_t n, uint32_t stride
 	if (n == 0) return TREEE_OK;
 	if (!rec || !xyz_out) return set_err(TREEE_ERR_INVALID, "treee_decode_las_records: null argument");
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
 	DevBuf<uint8_t> d_rec;
 	DevBuf<float> d_xyz;
@@ -148,7 +148,7 @@ int32_t treee_slice_keys(const float *xyz, uint64_t n, int64_t *key_out) {
 	if (n == 0) return TREEE_OK;
 	if (!xyz || !key_out) return set_err(TREEE_ERR_INVALID, "treee_slice_keys: null argument");
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
 	DevBuf<float> d_xyz;
 	DevBuf<int64_t> d_keys;
@@ -169,7 +169,7 @@ int32_t treee_slice_bin(const float *xyz, uint64_t n, int64_t *min_key_out, uint
 	if (!xyz) return set_err(TREEE_ERR_INVALID, "treee_slice_bin: xyz is null");
 	if (n >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n too large for one call");
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
 	hipStream_t st = ctx->stream;

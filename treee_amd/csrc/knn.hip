@@ -1085,7 +1085,7 @@ int32_t treee_knn_build(const float *xyz, uint64_t n, treee_knn **out) {
 	if (n == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");
 	if (!xyz) return set_err(TREEE_ERR_INVALID, "treee_knn_build: xyz is null");
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
 	DevBuf<float> d_xyz;
 	TREEE_TRY(d_xyz.alloc(n * 3));
@@ -1148,7 +1148,7 @@ int32_t treee_knn_query_batch(const treee_knn *t, const float *q, uint64_t nq, u
 	if (k == 0) return set_err(TREEE_ERR_INVALID, "k == 0 (the reference panics at best_set.rs:74)");
 	if (nq == 0) return TREEE_OK;
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
 	DevBuf<float> d_q, d_dist;
 	DevBuf<uint32_t> d_idx, d_cnt;
@@ -1186,7 +1186,7 @@ int32_t treee_curvature(const float *xyz, uint64_t n, uint32_t k, float max_dist
 	if (!xyz || !curve_out) return set_err(TREEE_ERR_INVALID, "treee_curvature: null argument");
 	if (k == 0) return set_err(TREEE_ERR_INVALID, "k == 0");
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	treee_knn *t = nullptr;
 	TREEE_TRY(treee_knn_build(xyz, n, &t));
 	DevBuf<float> d_curve;
@@ -1251,7 +1251,7 @@ extern "C" int32_t treee_knn_radius(const treee_knn *t, const float q[3], float 
                                     uint64_t *found_out) {
 	if (!t || !q || !found_out || (cap && !out)) return set_err(TREEE_ERR_INVALID, "treee_knn_radius: null argument");
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
 	const uint32_t n = (uint32_t)t->sc->n;

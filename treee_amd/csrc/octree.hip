@@ -244,7 +244,7 @@ int32_t treee_sort_build(const float *xyz, uint64_t n, const float corner[3], fl
                          uint32_t lod_cap, treee_octree **out) {
 	if (!out || (n && !xyz)) return set_err(TREEE_ERR_INVALID, "treee_sort_build: null argument");
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
 	DevBuf<float> d_xyz;
 	TREEE_TRY(d_xyz.alloc(n * 3));

@@ -217,7 +217,7 @@ int32_t treee_splat(const float *xyz, const uint32_t *value, uint64_t n, const f
                     uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h, float *depth_out, uint32_t *id_out) {
 	if (!view || !proj || (n && (!xyz || !value))) return set_err(TREEE_ERR_INVALID, "treee_splat: null argument");
 	treee_ctx *ctx = nullptr;
-	TREEE_TRY(default_ctx(&ctx));
+	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
 	const uint64_t px = (uint64_t)w * h;
 	DevBuf<float> d_xyz, d_depth;
