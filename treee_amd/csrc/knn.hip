@@ -656,20 +656,31 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 			// the own bucket's Morton neighbours were scanned above (the own bucket is no seed's descendant)
 			const bool leafhit = hit && node >= a.P && (node - a.P) < a.nb && node - a.P != start - 1u && node - a.P != start + 1u;
 			const bool innerhit = hit && node < a.P;
-			const uint64_t bl = __ballot(leafhit), bi = __ballot(innerhit);
+			// 4-ary step: a hit inner node expands straight to its four grandchildren (contiguous in the
+			// implicit layout) when they exist, which halves the number of dependent BFS rounds
+			const bool deep = innerhit && 2u * node < a.P;
+			const bool shallow = innerhit && !deep;
+			const uint64_t bl = __ballot(leafhit), b4 = __ballot(deep), b2 = __ballot(shallow);
 			if (leafhit) {
 				const uint32_t o = list_m + __popcll(bl & lt_mask);
 				if (o < (uint32_t)LIST_CAP) s_list[o] = node - a.P;
 			}
 			if (innerhit) {
-				const uint32_t o = next_m + 2u * __popcll(bi & lt_mask);
-				if (o + 1u < (uint32_t)FRONT_CAP) {
+				const uint32_t o = next_m + 4u * __popcll(b4 & lt_mask) + 2u * __popcll(b2 & lt_mask);
+				if (deep) {
+					if (o + 3u < (uint32_t)FRONT_CAP) {
+						nxt[o] = 4u * node;
+						nxt[o + 1u] = 4u * node + 1u;
+						nxt[o + 2u] = 4u * node + 2u;
+						nxt[o + 3u] = 4u * node + 3u;
+					}
+				} else if (o + 1u < (uint32_t)FRONT_CAP) {
 					nxt[o] = 2u * node;
 					nxt[o + 1u] = 2u * node + 1u;
 				}
 			}
 			list_m += __popcll(bl);
-			next_m += 2u * __popcll(bi);
+			next_m += 4u * __popcll(b4) + 2u * __popcll(b2);
 			ST(st_nodes++);
 		}
 		if (list_m > (uint32_t)LIST_CAP || next_m > (uint32_t)FRONT_CAP) {
