@@ -28,6 +28,7 @@ struct treee_knn {
 	uint32_t nb = 0;       // buckets of 64 points
 	uint32_t P = 1;        // leaves padded to a power of two; node i: children 2i, 2i+1; leaf b = P + b
 	float4 *d_bvh = nullptr; // [2P][2] : (min.xyz,0), (max.xyz,0)
+	uint32_t *d_order = nullptr; // buckets ordered by decreasing box size class (stable within a class)
 	int device = 0;
 	treee_ctx *owner = nullptr;
 };
@@ -172,6 +173,7 @@ struct KnnArgs {
 	const float *q_xyz;          // AoS, original order
 	const uint32_t *q_order;     // sorted query slot -> original query index
 	const uint32_t *q_start;     // per wave: start bucket
+	const uint32_t *wave_order;  // self mode: bucket handled by workgroup i (largest boxes first), or null
 	uint32_t nq;
 	uint32_t k, maxbits;
 	float *out_dist;
@@ -428,7 +430,11 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 	const int lane = threadIdx.x;
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-	const uint32_t slot = blockIdx.x * 64u + lane;
+	// self mode: workgroups take the buckets with the largest boxes first (they are the expensive ones:
+	// sparse regions and buckets that straddle a jump of the Morton curve), so that no straggler starts
+	// near the end of the kernel
+	const uint32_t wave_id = (!a.q_xyz && a.wave_order) ? a.wave_order[blockIdx.x] : blockIdx.x;
+	const uint32_t slot = wave_id * 64u + lane;
 	const bool live = slot < a.nq;
 	float qx = 0.0f, qy = 0.0f, qz = 0.0f;
 	uint32_t row = 0, start;
@@ -448,7 +454,7 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 			qz = p.z;
 			row = __float_as_uint(p.w);
 		}
-		start = blockIdx.x;
+		start = wave_id;
 	}
 	// dead lanes never pass the filter: NaN query -> NaN distance
 	if (!live) qx = __uint_as_float(0x7FC00000u);
@@ -963,6 +969,8 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	a.q_xyz = nullptr;
 	a.q_order = nullptr;
 	a.q_start = nullptr;
+	static const bool no_order = getenv("TREEE_KNN_NO_ORDER") != nullptr; // A/B hook
+	a.wave_order = no_order ? nullptr : t->d_order;
 	a.nq = (uint32_t)nq;
 	a.k = k;
 	a.maxbits = max_bits(max_dist_sq);
@@ -1031,6 +1039,17 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	return TREEE_OK;
 }
 
+// size class of a bucket: 255 - exponent byte of its squared box diagonal (small key = large box)
+__global__ __launch_bounds__(256) void k_bucket_class(const float4 *__restrict__ bvh, uint32_t nb, uint32_t P, uint32_t *__restrict__ key) {
+	const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+	if (b >= nb) return;
+	const float4 lo = bvh[2ull * (P + b) + 0], hi = bvh[2ull * (P + b) + 1];
+	const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+	const float d2 = dx * dx + dy * dy + dz * dz;
+	const uint32_t e = (d2 == d2 && d2 > 0.0f) ? ((__float_as_uint(d2) >> 23) & 255u) : 0u;
+	key[b] = 255u - e;
+}
+
 int32_t build_bvh(treee_ctx *ctx, treee_knn *t) {
 	const uint64_t n = t->sc->n;
 	t->nb = div_up(n, BUCKET);
@@ -1042,6 +1061,14 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t) {
 	for (uint32_t lvl = t->P >> 1; lvl >= 1; lvl >>= 1) // nodes [lvl, 2*lvl)
 		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
 	TREEE_LAUNCH_CHECK();
+	// dispatch order of the self-query kernel: one 8-bit stable radix pass over the buckets
+	uint32_t *d_key = nullptr, *d_key_sorted = nullptr;
+	TREEE_TRY(ctx->alloc_t(t->nb, &d_key));
+	TREEE_TRY(ctx->alloc_t(t->nb, &d_key_sorted));
+	TREEE_TRY(pool_alloc_t(ctx, t->nb, &t->d_order));
+	hipLaunchKernelGGL(k_bucket_class, dim3(div_up(t->nb, 256)), dim3(256), 0, ctx->stream, t->d_bvh, t->nb, t->P, d_key);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(sort_pairs_dev(ctx, d_key, nullptr, t->nb, 8, d_key_sorted, t->d_order));
 	return TREEE_OK;
 }
 
@@ -1111,6 +1138,7 @@ int32_t treee_knn_free(treee_knn *t) {
 	(void)hipSetDevice(t->device);
 	t->sc.reset();
 	pool_release(t->owner, t->d_bvh);
+	pool_release(t->owner, t->d_order);
 	delete t;
 	return TREEE_OK;
 }
