@@ -113,7 +113,7 @@ def main():
     def step(record):
         nonlocal halo
         if world > 1:
-            ghosts = stages.run("ghost_allgather", lambda: D.exchange_ghosts(pts, bounds, halo, rank, world), record)
+            ghosts = stages.run("ghost_allgather", lambda: D.exchange_ghosts(pts, bounds, halo, rank, world, ctx=ctx), record)
             cloud = torch.cat([pts, ghosts]) if ghosts.shape[0] else pts
         else:
             cloud = pts

@@ -196,6 +196,14 @@ int32_t treee_slice_bin(const float *xyz_aos, uint64_t n, int64_t *min_key_out,
                         uint64_t *layers_out, uint32_t *order_out, uint64_t *offsets_out,
                         uint64_t offsets_cap);
 
+/* ---- E: spatial shards (multi-GPU; no reference counterpart -- the reference is one process) ---- */
+/* Stable compaction of the points whose (x, z) is inside keep_box = {x0, x1, z0, z1} (half-open) and NOT
+ * inside drop_box.  Boundary points of a tile: keep = everything, drop = the tile shrunk by the halo on
+ * its shared faces; ghosts from peers: keep = the dilated tile, drop = an empty box.  NaN never passes.
+ * Writes min(count, cap) points in input order; *d_count_out (device u32) = count. */
+int32_t treee_select_xz_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, const float keep_box[4],
+                            const float drop_box[4], float *d_out_xyz, uint64_t cap, uint32_t *d_count_out);
+
 #ifdef __cplusplus
 }
 #endif

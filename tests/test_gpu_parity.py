@@ -481,3 +481,28 @@ def test_host_api_is_thread_safe(T, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_shard_selection_matches_torch(T):
+    """the fused boundary / ghost selection of the multi-GPU path vs the torch expressions it replaces"""
+    import torch
+
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    for rank, world in ((0, 2), (5, 8), (3, 4)):
+        plot, halo = 30.0, 1.5
+        pts, _ = synth.forest_cloud_torch(120_000, "cuda", plot=plot, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, plot))
+        bounds, faces = D.tile_bounds(rank, world, plot), D._interior_faces(rank, world)
+        x0, x1, z0, z1 = bounds
+        inf = float("inf")
+        interior = (x0 + halo if faces[0] else -inf, x1 - halo if faces[1] else inf, z0 + halo if faces[2] else -inf, z1 - halo if faces[3] else inf)
+        got = D.select_xz(pts, (-inf, inf, -inf, inf), interior)
+        ref = pts[D.select_boundary(pts, bounds, faces, halo)]
+        assert torch.equal(got, ref) and got.shape[0] > 1000
+        padded = torch.cat([pts[:5000], torch.full((100, 3), float("nan"), device="cuda"), pts[5000:9000]])
+        got = D.select_xz(padded, (x0 + 3.0, x1 - 4.0, z0 - halo, z1 + halo), (0.0, 0.0, 0.0, 0.0))
+        p = padded
+        m = (p[:, 0] >= x0 + 3.0) & (p[:, 0] < x1 - 4.0) & (p[:, 2] >= z0 - halo) & (p[:, 2] < z1 + halo)
+        assert torch.equal(got, p[m])
+    assert D.select_xz(pts[:0], (-inf, inf, -inf, inf), (0.0, 0.0, 0.0, 0.0)).shape[0] == 0

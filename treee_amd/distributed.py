@@ -97,27 +97,58 @@ def select_boundary(points, bounds, faces, halo):
     return m
 
 
-def exchange_ghosts(points, bounds, halo, rank, world_size, group=None):
+_INF = float("inf")
+
+
+def select_xz(points, keep_box, drop_box, ctx=None):
+    """points (float32 [n,3], CUDA) whose (x, z) is inside keep_box and not inside drop_box, in input
+    order: the library's fused flag / scan / compact (treee_select_xz_dev).  Synchronises to learn the count."""
+    import numpy as np
+
+    from . import _lib
+    from .context import default_context, ptr
+
+    pts = points.contiguous()
+    n = pts.shape[0]
+    c = ctx or default_context(pts.device)
+    out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=pts.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=pts.device)
+    keep = np.asarray(keep_box, dtype=np.float32)
+    drop = np.asarray(drop_box, dtype=np.float32)
+    _lib.check(_lib.lib().treee_select_xz_dev(c.handle, ptr(pts), n, ptr(keep), ptr(drop), ptr(out), n, ptr(count)))
+    return out[: int(count.item())]
+
+
+def exchange_ghosts(points, bounds, halo, rank, world_size, group=None, ctx=None):
     """the ghost-point all-gather.  Returns the ghosts (float32 [g,3]) that lie inside this
-    rank's tile dilated by `halo` (own points excluded)."""
+    rank's tile dilated by `halo` (own points excluded).  CUDA tensors go through the library's fused
+    selection kernels; CPU tensors (gloo tests) through the equivalent torch expressions."""
     if world_size == 1:
         return points[:0]
     faces = _interior_faces(rank, world_size)
-    mine = points[select_boundary(points, bounds, faces, halo)].contiguous()
+    x0, x1, z0, z1 = bounds
+    if points.is_cuda:
+        interior = (x0 + halo if faces[0] else -_INF, x1 - halo if faces[1] else _INF, z0 + halo if faces[2] else -_INF, z1 - halo if faces[3] else _INF)
+        mine = select_xz(points, (-_INF, _INF, -_INF, _INF), interior, ctx)
+    else:
+        mine = points[select_boundary(points, bounds, faces, halo)].contiguous()
     count = torch.tensor([mine.shape[0]], dtype=torch.int64, device=points.device)
     counts = [int(c) for c in _all_gather_equal(count, world_size, group).flatten().tolist()]
     cap = max(max(counts), 1)
-    send = torch.zeros((cap, 3), dtype=torch.float32, device=points.device)
+    send = torch.full((cap, 3), float("nan"), dtype=torch.float32, device=points.device)  # NaN padding is never selected
     send[: mine.shape[0]] = mine
     recv = _all_gather_equal(send, world_size, group)  # padded: RCCL all-gather needs equal counts
-    x0, x1, z0, z1 = bounds
+    dilated = (x0 - halo, x1 + halo, z0 - halo, z1 + halo)
     keep = []
-    for r in range(world_size):
-        if r == rank or counts[r] == 0:
+    for part in (recv[:rank], recv[rank + 1 :]):  # every peer's block, own block skipped
+        flat = part.reshape(-1, 3)
+        if flat.shape[0] == 0:
             continue
-        g = recv[r, : counts[r]]
-        inside = (g[:, 0] >= x0 - halo) & (g[:, 0] < x1 + halo) & (g[:, 2] >= z0 - halo) & (g[:, 2] < z1 + halo)
-        keep.append(g[inside])
+        if points.is_cuda:
+            keep.append(select_xz(flat, dilated, (0.0, 0.0, 0.0, 0.0), ctx))
+        else:
+            inside = (flat[:, 0] >= dilated[0]) & (flat[:, 0] < dilated[1]) & (flat[:, 2] >= dilated[2]) & (flat[:, 2] < dilated[3])
+            keep.append(flat[inside])
     return torch.cat(keep) if keep else points[:0]
 
 
