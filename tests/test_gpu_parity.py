@@ -506,3 +506,25 @@ def test_shard_selection_matches_torch(T):
         m = (p[:, 0] >= x0 + 3.0) & (p[:, 0] < x1 - 4.0) & (p[:, 2] >= z0 - halo) & (p[:, 2] < z1 + halo)
         assert torch.equal(got, p[m])
     assert D.select_xz(pts[:0], (-inf, inf, -inf, inf), (0.0, 0.0, 0.0, 0.0)).shape[0] == 0
+
+
+def test_onesweep_sort_variant_bit_exact(T):
+    """the optional onesweep radix passes (decoupled look-back across workgroups, TREEE_SORT_ONESWEEP=1)
+    must give the same bits as the default hist/scan/scatter passes"""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import numpy as np, hashlib, treee_amd as T\n"
+            "from treee_amd import synth\n"
+            "p,_=synth.forest_cloud(700_001, plot=40.0)\n"
+            "o=T.Octree(p); print(hashlib.sha256(o.array('keys').tobytes()+o.array('perm').tobytes()+o.array('leaf').tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for flag in (False, True):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("TREEE_SORT_ONESWEEP", None)
+        if flag:
+            env["TREEE_SORT_ONESWEEP"] = "1"
+        out.append(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip().splitlines()[-1])
+    assert out[0] == out[1]
