@@ -241,11 +241,12 @@ def main():
 
 def measured_traffic(points):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json: FETCH_SIZE raw + WRITE_SIZE); only valid for the profiled size."""
+    (profiles/r01_traffic.json: 2 x FETCH_SIZE raw, the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE);
+    only valid for the profiled size."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
         if t["points_per_launch"] == points:
-            return int(t["fetch_size_bytes_raw"] + t["write_size_bytes"])
+            return int(2 * t["fetch_size_bytes_raw"] + t["write_size_bytes"])
     except Exception:
         pass
     return None

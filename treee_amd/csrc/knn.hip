@@ -28,7 +28,8 @@ struct treee_knn {
 	uint32_t nb = 0;       // buckets of 64 points
 	uint32_t P = 1;        // leaves padded to a power of two; node i: children 2i, 2i+1; leaf b = P + b
 	float4 *d_bvh = nullptr; // [2P][2] : (min.xyz,0), (max.xyz,0)
-	uint32_t *d_order = nullptr; // buckets ordered by decreasing box size class (stable within a class)
+	uint32_t *d_order = nullptr; // workgroup -> bucket of the self-query kernel (build_bvh), ~0u = padding
+	uint32_t n_order = 0;        // its length (8 * the longest XCD segment)
 	int device = 0;
 	treee_ctx *owner = nullptr;
 };
@@ -406,6 +407,9 @@ template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef TREEE_ORDER_RANGE
+#define TREEE_ORDER_RANGE 128
+#endif
 #ifndef TREEE_LIST_CAP
 #define TREEE_LIST_CAP 512
 #endif
@@ -433,7 +437,10 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 	// self mode: workgroups take the buckets with the largest boxes first (they are the expensive ones:
 	// sparse regions and buckets that straddle a jump of the Morton curve), so that no straggler starts
 	// near the end of the kernel
+	// and the workgroups that share an XCD (blockIdx % 8) walk the same Morton ranges, so its L2 serves the
+	// bucket re-reads of neighbouring waves (build_bvh lays the table out that way; ~0u = padding)
 	const uint32_t wave_id = (!a.q_xyz && a.wave_order) ? a.wave_order[blockIdx.x] : blockIdx.x;
+	if (wave_id == ~0u) return;
 	const uint32_t slot = wave_id * 64u + lane;
 	const bool live = slot < a.nq;
 	float qx = 0.0f, qy = 0.0f, qz = 0.0f;
@@ -986,7 +993,7 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		TREEE_TRY(ctx->alloc_t(64, &a.stats));
 		TREEE_HIP(hipMemsetAsync(a.stats, 0, 256, ctx->stream));
 	}
-	const uint32_t nwaves = div_up(nq, 64);
+	uint32_t nwaves = div_up(nq, 64);
 	if (d_q) { // external queries: Morton-sort them so that a wave is spatially compact
 		uint32_t *d_qk = nullptr, *d_qks = nullptr, *d_qo = nullptr, *d_qs = nullptr;
 		TREEE_TRY(ctx->alloc_t(nq, &d_qk));
@@ -1003,11 +1010,13 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	}
 	static const bool force_heap = getenv("TREEE_KNN_FORCE_HEAP") != nullptr; // A/B and test hook
 	if (k <= (uint32_t)SK && !force_heap) {
+		if (a.wave_order && !d_q) nwaves = t->n_order; // padded dispatch table
 		if (a.stats)
 			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
 		else
 			hipLaunchKernelGGL(k_knn_sorted32<false>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
 	} else {
+		a.wave_order = nullptr;
 		if (lds > 64 * 1024)
 			TREEE_HIP(hipFuncSetAttribute((const void *)k_knn_heap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		hipLaunchKernelGGL(k_knn_heap, dim3(nwaves), dim3(64), lds, ctx->stream, a);
@@ -1039,7 +1048,10 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	return TREEE_OK;
 }
 
-// size class of a bucket: 255 - exponent byte of its squared box diagonal (small key = large box)
+// dispatch key of a bucket: (XCD label of its Morton range) << 8 | size class, where the size class is
+// 255 - exponent byte of its squared box diagonal (small key = large box) and ranges of ORDER_RANGE buckets
+// are dealt to the 8 XCD labels in turn
+constexpr uint32_t ORDER_RANGE = TREEE_ORDER_RANGE;
 __global__ __launch_bounds__(256) void k_bucket_class(const float4 *__restrict__ bvh, uint32_t nb, uint32_t P, uint32_t *__restrict__ key) {
 	const uint32_t b = blockIdx.x * 256u + threadIdx.x;
 	if (b >= nb) return;
@@ -1047,7 +1059,24 @@ __global__ __launch_bounds__(256) void k_bucket_class(const float4 *__restrict__
 	const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
 	const float d2 = dx * dx + dy * dy + dz * dz;
 	const uint32_t e = (d2 == d2 && d2 > 0.0f) ? ((__float_as_uint(d2) >> 23) & 255u) : 0u;
-	key[b] = 255u - e;
+	key[b] = (((b / ORDER_RANGE) & 7u) << 8) | (255u - e);
+}
+
+// number of buckets with XCD label x, and of those with a smaller label
+__device__ __host__ inline uint32_t order_count(uint32_t nb, uint32_t x) {
+	const uint32_t nr = nb / ORDER_RANGE, rem = nb % ORDER_RANGE;
+	return (nr / 8u + (x < nr % 8u ? 1u : 0u)) * ORDER_RANGE + (x == nr % 8u ? rem : 0u);
+}
+
+// table[slot * 8 + x] = slot-th bucket of label x in (class, Morton) order: the hardware deals consecutive
+// workgroups to the XCDs in turn, so the workgroups of one XCD walk one label
+__global__ __launch_bounds__(256) void k_order_interleave(const uint32_t *__restrict__ sorted, uint32_t nb, uint32_t len, uint32_t *__restrict__ table) {
+	const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+	if (p >= len) return;
+	const uint32_t x = p & 7u, slot = p >> 3;
+	uint32_t start = 0;
+	for (uint32_t i = 0; i < x; ++i) start += order_count(nb, i);
+	table[p] = slot < order_count(nb, x) ? sorted[start + slot] : ~0u;
 }
 
 int32_t build_bvh(treee_ctx *ctx, treee_knn *t) {
@@ -1061,14 +1090,21 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t) {
 	for (uint32_t lvl = t->P >> 1; lvl >= 1; lvl >>= 1) // nodes [lvl, 2*lvl)
 		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
 	TREEE_LAUNCH_CHECK();
-	// dispatch order of the self-query kernel: one 8-bit stable radix pass over the buckets
-	uint32_t *d_key = nullptr, *d_key_sorted = nullptr;
+	// dispatch table of the self-query kernel: a stable radix sort of the buckets by (XCD label, size class),
+	// then the 8 label segments interleaved
+	uint32_t *d_key = nullptr, *d_key_sorted = nullptr, *d_sorted = nullptr;
+	uint32_t longest = 0;
+	for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, order_count(t->nb, x));
+	t->n_order = 8u * longest;
 	TREEE_TRY(ctx->alloc_t(t->nb, &d_key));
 	TREEE_TRY(ctx->alloc_t(t->nb, &d_key_sorted));
-	TREEE_TRY(pool_alloc_t(ctx, t->nb, &t->d_order));
+	TREEE_TRY(ctx->alloc_t(t->nb, &d_sorted));
+	TREEE_TRY(pool_alloc_t(ctx, t->n_order, &t->d_order));
 	hipLaunchKernelGGL(k_bucket_class, dim3(div_up(t->nb, 256)), dim3(256), 0, ctx->stream, t->d_bvh, t->nb, t->P, d_key);
 	TREEE_LAUNCH_CHECK();
-	TREEE_TRY(sort_pairs_dev(ctx, d_key, nullptr, t->nb, 8, d_key_sorted, t->d_order));
+	TREEE_TRY(sort_pairs_dev(ctx, d_key, nullptr, t->nb, 11, d_key_sorted, d_sorted));
+	hipLaunchKernelGGL(k_order_interleave, dim3(div_up(t->n_order, 256)), dim3(256), 0, ctx->stream, d_sorted, t->nb, t->n_order, t->d_order);
+	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
 }
 
