@@ -230,6 +230,9 @@ def main():
             "stages": stage_roof,
             "end_to_end_GBps": round((sum(BYTES.values()) * n + 24 * W * H) / (elapsed / args.steps) / 1e9 * world, 1),
         }
+        if world == 1:
+            out["hbm_copy_GBps"] = measured_copy_gbps(dev)
+            out["ingest"] = ingest_stage(n, dev, ctx)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -237,6 +240,64 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_copy_gbps(dev):
+    """Practical HBM ceiling beside the 8 TB/s spec: device-to-device copy of 1 GiB, read + write bytes."""
+    a = torch.empty((1 << 28,), dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
+def ingest_stage(n, dev, ctx):
+    """Rows A8/A9 beside the step (not part of `value`): decode n LAS format-0 records (20 B, laz.rs:202-213) that are
+    resident in HBM, then y-slice keys + binning (loading.rs:97-101).  Algorithmic bytes: decode reads the 12
+    coordinate bytes of a record and writes 12; binning reads y (4), writes + sorts (key, index) pairs in
+    ceil(bits/8) passes of 16 B, and writes the order (4)."""
+    import treee_amd as T
+    from treee_amd import laz
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    rec = torch.zeros((n, 5), dtype=torch.int32, device=dev)
+    rec[:, 0] = torch.randint(-100_000, 100_000, (n,), generator=g, device=dev, dtype=torch.int32)
+    rec[:, 1] = torch.randint(-100_000, 100_000, (n,), generator=g, device=dev, dtype=torch.int32)
+    rec[:, 2] = torch.randint(0, 30_000, (n,), generator=g, device=dev, dtype=torch.int32)
+    raw = rec.view(torch.uint8).reshape(-1)
+    chunk = laz.Chunk(raw, 20, (0.0, 0.0, 0.0), (0.001, 0.001, 0.001), (0.0, 0.0, 15.0))
+    res = {}
+    for name, fn in (("decode", lambda: chunk.read(ctx)), ("slice_bin", None)):
+        if fn is None:
+            pts = chunk.read(ctx)
+            fn = lambda: laz.slice_bin(pts, ctx)  # noqa: E731
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / 3
+    layers = out[2].shape[0] - 1
+    passes = max(1, (max(1, (layers - 1).bit_length()) + 7) // 8)
+    b_dec, b_bin = 24, 4 + 8 + 16 * passes + 4
+    return {
+        "workload": f"{n} LAS fmt-0 records (20 B) resident in HBM -> xyz f32 -> {layers} y-slices",
+        "decode_ms": round(res["decode"], 3),
+        "decode_GBps": round(b_dec * n / (res["decode"] * 1e-3) / 1e9, 1),
+        "decode_frac": round(b_dec * n / (res["decode"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "slice_bin_ms": round(res["slice_bin"], 3),
+        "slice_bin_GBps": round(b_bin * n / (res["slice_bin"] * 1e-3) / 1e9, 1),
+        "slice_bin_frac": round(b_bin * n / (res["slice_bin"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "Mpoints_per_s": round(n / ((res["decode"] + res["slice_bin"]) * 1e-3) / 1e6, 1),
+    }
 
 
 def measured_traffic(points):

@@ -195,6 +195,11 @@ int32_t treee_slice_keys_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n,
 int32_t treee_slice_bin(const float *xyz_aos, uint64_t n, int64_t *min_key_out,
                         uint64_t *layers_out, uint32_t *order_out, uint64_t *offsets_out,
                         uint64_t offsets_cap);
+/* device form: d_order_out[n] u32 and d_offsets_out[offsets_cap] u64 are device arrays; the
+ * layer count is returned through one stream synchronisation (it sizes the offsets array) */
+int32_t treee_slice_bin_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, int64_t *min_key_out,
+                            uint64_t *layers_out, uint32_t *d_order_out, uint64_t *d_offsets_out,
+                            uint64_t offsets_cap);
 
 /* ---- E: spatial shards (multi-GPU; no reference counterpart -- the reference is one process) ---- */
 /* Stable compaction of the points whose (x, z) is inside keep_box = {x0, x1, z0, z1} (half-open) and NOT

@@ -297,6 +297,13 @@ def test_slice_keys_and_binning(T, oracle):
     mn, order, offsets = T.slice_bin(pts)
     rmn, rorder, roffsets = oracle.slice_bin(pts)
     assert mn == rmn and np.array_equal(offsets, roffsets) and np.array_equal(order.astype(np.uint64), rorder)
+    # device-resident form: same answer without the host copies
+    import torch
+
+    dmn, dorder, doffsets = T.slice_bin(torch.from_numpy(pts).cuda())
+    assert dmn == rmn
+    assert np.array_equal(doffsets.cpu().numpy().astype(np.uint64), roffsets)
+    assert np.array_equal(dorder.cpu().numpy().view(np.uint32).astype(np.uint64), rorder)
 
 
 # ---------------------------------------------------------------- full-size properties (cfg 2/3)

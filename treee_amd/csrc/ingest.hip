@@ -161,6 +161,49 @@ int32_t treee_slice_keys(const float *xyz, uint64_t n, int64_t *key_out) {
 	return TREEE_OK;
 }
 
+int32_t treee_slice_bin_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, int64_t *min_key_out, uint64_t *layers_out, uint32_t *d_order_out,
+                            uint64_t *d_offsets_out, uint64_t offsets_cap) {
+	if (!ctx || !layers_out) return set_err(TREEE_ERR_INVALID, "treee_slice_bin_dev: null argument");
+	*layers_out = 0;
+	if (n == 0) return TREEE_OK;
+	if (!d_xyz) return set_err(TREEE_ERR_INVALID, "treee_slice_bin_dev: xyz is null");
+	if (n >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n too large for one call");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	hipStream_t st = ctx->stream;
+	long long *d_keys = nullptr, *d_mm = nullptr;
+	TREEE_TRY(ctx->alloc_t(n, &d_keys));
+	TREEE_TRY(ctx->alloc_t(2, &d_mm));
+	hipLaunchKernelGGL(k_slice_keys, dim3(div_up(n, 256)), dim3(256), 0, st, d_xyz, (uint32_t)n, d_keys);
+	const long long init[2] = {0x7FFFFFFFFFFFFFFFll, (long long)0x8000000000000000ull};
+	TREEE_HIP(hipMemcpyAsync(d_mm, init, 16, hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_minmax_i64, dim3(n < 262144 ? div_up(n, 256) : 1024), dim3(256), 0, st, d_keys, (uint32_t)n, d_mm);
+	TREEE_LAUNCH_CHECK();
+	long long mm[2];
+	TREEE_HIP(hipMemcpyAsync(mm, d_mm, 16, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipStreamSynchronize(st)); // the layer count sizes the caller's offsets array
+	const unsigned long long span = (unsigned long long)mm[1] - (unsigned long long)mm[0];
+	if (span >= (1ull << 24))
+		return set_err(TREEE_ERR_UNSUPPORTED, "slice key range %llu too large (the reference would allocate one Vec per layer)", span + 1);
+	const uint32_t layers = (uint32_t)span + 1;
+	*layers_out = layers;
+	if (min_key_out) *min_key_out = mm[0];
+	if (!d_offsets_out && !d_order_out) return TREEE_OK;
+	if (d_offsets_out && offsets_cap < (uint64_t)layers + 1) return set_err(TREEE_ERR_INVALID, "offsets_cap %llu < layers+1 = %u", (unsigned long long)offsets_cap, layers + 1);
+	uint32_t *d_k32 = nullptr, *d_ks = nullptr, *d_order = d_order_out;
+	unsigned long long *d_off = (unsigned long long *)d_offsets_out;
+	TREEE_TRY(ctx->alloc_t(n, &d_k32));
+	TREEE_TRY(ctx->alloc_t(n, &d_ks));
+	if (!d_order) TREEE_TRY(ctx->alloc_t(n, &d_order));
+	hipLaunchKernelGGL(k_offset_keys, dim3(div_up(n, 256)), dim3(256), 0, st, d_keys, (uint32_t)n, mm[0], d_k32);
+	int bits = 0;
+	while ((1ull << bits) < layers) ++bits;
+	TREEE_TRY(sort_pairs_dev(ctx, d_k32, nullptr, n, bits, d_ks, d_order));
+	if (d_off) hipLaunchKernelGGL(k_slice_offsets, dim3(div_up((uint64_t)layers + 1, 256)), dim3(256), 0, st, d_ks, (uint32_t)n, layers, d_off);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
 int32_t treee_slice_bin(const float *xyz, uint64_t n, int64_t *min_key_out, uint64_t *layers_out, uint32_t *order_out,
                         uint64_t *offsets_out, uint64_t offsets_cap) {
 	if (!layers_out) return set_err(TREEE_ERR_INVALID, "treee_slice_bin: layers_out is null");
@@ -171,45 +214,17 @@ int32_t treee_slice_bin(const float *xyz, uint64_t n, int64_t *min_key_out, uint
 	treee_ctx *ctx = nullptr;
 	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));
-	TREEE_TRY(ctx->reset());
-	hipStream_t st = ctx->stream;
-	float *d_xyz = nullptr;
-	long long *d_keys = nullptr, *d_mm = nullptr;
-	TREEE_TRY(ctx->alloc_t(n * 3, &d_xyz));
-	TREEE_TRY(ctx->alloc_t(n, &d_keys));
-	TREEE_TRY(ctx->alloc_t(2, &d_mm));
-	TREEE_HIP(hipMemcpyAsync(d_xyz, xyz, n * 12, hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_slice_keys, dim3(div_up(n, 256)), dim3(256), 0, st, d_xyz, (uint32_t)n, d_keys);
-	const long long init[2] = {0x7FFFFFFFFFFFFFFFll, (long long)0x8000000000000000ull};
-	TREEE_HIP(hipMemcpyAsync(d_mm, init, 16, hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_minmax_i64, dim3(n < 262144 ? div_up(n, 256) : 1024), dim3(256), 0, st, d_keys, (uint32_t)n, d_mm);
-	TREEE_LAUNCH_CHECK();
-	long long mm[2];
-	TREEE_HIP(hipMemcpyAsync(mm, d_mm, 16, hipMemcpyDeviceToHost, st));
-	TREEE_HIP(hipStreamSynchronize(st));
-	const unsigned long long span = (unsigned long long)mm[1] - (unsigned long long)mm[0];
-	if (span >= (1ull << 24))
-		return set_err(TREEE_ERR_UNSUPPORTED, "slice key range %llu too large (the reference would allocate one Vec per layer)", span + 1);
-	const uint32_t layers = (uint32_t)span + 1;
-	*layers_out = layers;
-	if (min_key_out) *min_key_out = mm[0];
-	if (!offsets_out && !order_out) return TREEE_OK;
-	if (offsets_out && offsets_cap < (uint64_t)layers + 1) return set_err(TREEE_ERR_INVALID, "offsets_cap %llu < layers+1 = %u", (unsigned long long)offsets_cap, layers + 1);
-	uint32_t *d_k32 = nullptr, *d_ks = nullptr, *d_order = nullptr;
-	unsigned long long *d_off = nullptr;
-	TREEE_TRY(ctx->alloc_t(n, &d_k32));
-	TREEE_TRY(ctx->alloc_t(n, &d_ks));
-	TREEE_TRY(ctx->alloc_t(n, &d_order));
-	TREEE_TRY(ctx->alloc_t((size_t)layers + 1, &d_off));
-	hipLaunchKernelGGL(k_offset_keys, dim3(div_up(n, 256)), dim3(256), 0, st, d_keys, (uint32_t)n, mm[0], d_k32);
-	int bits = 0;
-	while ((1ull << bits) < layers) ++bits;
-	TREEE_TRY(sort_pairs_dev(ctx, d_k32, nullptr, n, bits, d_ks, d_order));
-	hipLaunchKernelGGL(k_slice_offsets, dim3(div_up((uint64_t)layers + 1, 256)), dim3(256), 0, st, d_ks, (uint32_t)n, layers, d_off);
-	TREEE_LAUNCH_CHECK();
-	if (order_out) TREEE_HIP(hipMemcpyAsync(order_out, d_order, n * 4, hipMemcpyDeviceToHost, st));
-	if (offsets_out) TREEE_HIP(hipMemcpyAsync(offsets_out, d_off, ((size_t)layers + 1) * 8, hipMemcpyDeviceToHost, st));
-	TREEE_HIP(hipStreamSynchronize(st));
+	DevBuf<float> d_xyz;
+	DevBuf<uint32_t> d_order;
+	DevBuf<uint64_t> d_off;
+	TREEE_TRY(d_xyz.alloc(n * 3));
+	TREEE_HIP(hipMemcpyAsync(d_xyz.p, xyz, n * 12, hipMemcpyHostToDevice, ctx->stream));
+	if (order_out) TREEE_TRY(d_order.alloc(n));
+	if (offsets_out) TREEE_TRY(d_off.alloc(offsets_cap ? offsets_cap : 1));
+	TREEE_TRY(treee_slice_bin_dev(ctx, d_xyz.p, n, min_key_out, layers_out, d_order.p, d_off.p, offsets_cap));
+	if (order_out) TREEE_HIP(hipMemcpyAsync(order_out, d_order.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+	if (offsets_out) TREEE_HIP(hipMemcpyAsync(offsets_out, d_off.p, ((size_t)*layers_out + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+	TREEE_HIP(hipStreamSynchronize(ctx->stream));
 	return TREEE_OK;
 }
 

@@ -121,11 +121,28 @@ def slice_keys(points, ctx=None):
     return out
 
 
-def slice_bin(points):
+def slice_bin(points, ctx=None):
     """Shared.slices (loading.rs:28,97-101) densified like segmenting.rs:121-133.
-    Returns (min_key, order[n] u32, offsets[layers+1] u64)."""
+    Returns (min_key, order[n] u32, offsets[layers+1] u64); device tensors for a device cloud."""
     import ctypes as C
 
+    if is_device(points):
+        import torch
+
+        p = dev_f32(points, 3)
+        c = ctx or default_context(p.device)
+        n = p.shape[0]
+        mn, layers = C.c_int64(0), C.c_uint64(0)
+        order = torch.empty((n,), dtype=torch.int32, device=p.device)
+        offsets = torch.empty((4097,), dtype=torch.int64, device=p.device)  # one call unless the cloud has > 4096 layers
+        if n:
+            rc = _lib.lib().treee_slice_bin_dev(c.handle, ptr(p), n, C.byref(mn), C.byref(layers), ptr(order), ptr(offsets), offsets.shape[0])
+            if rc != 0 and layers.value + 1 > offsets.shape[0]:
+                offsets = torch.empty((layers.value + 1,), dtype=torch.int64, device=p.device)
+                rc = _lib.lib().treee_slice_bin_dev(c.handle, ptr(p), n, C.byref(mn), C.byref(layers), ptr(order), ptr(offsets), offsets.shape[0])
+            _lib.check(rc)
+        offsets = offsets[: layers.value + 1 if n else 0]
+        return int(mn.value), order, offsets
     p = host_f32(points, 3)
     n = len(p)
     mn, layers = C.c_int64(0), C.c_uint64(0)
