@@ -233,6 +233,7 @@ def main():
         if world == 1:
             out["hbm_copy_GBps"] = measured_copy_gbps(dev)
             out["ingest"] = ingest_stage(n, dev, ctx)
+            out["per_segment_knn"] = segment_stage(pts, seg, ctx)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -297,6 +298,41 @@ def ingest_stage(n, dev, ctx):
         "slice_bin_GBps": round(b_bin * n / (res["slice_bin"] * 1e-3) / 1e9, 1),
         "slice_bin_frac": round(b_bin * n / (res["slice_bin"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "Mpoints_per_s": round(n / ((res["decode"] + res["slice_bin"]) * 1e-3) / 1e6, 1),
+    }
+
+
+def segment_stage(pts, seg, ctx):
+    """The kNN + curvature loop the way the reference calls it -- one KD-tree per segment (calculations.rs:97-118,
+    329) -- for all segments of the same cloud in one pass (treee_knn_build_segments_dev + treee_curvature_dev).
+    Beside the step, not part of `value`."""
+    import treee_amd as T
+
+    n = pts.shape[0]
+    nseg = int(seg.max().item()) + 1
+    out = torch.empty((n,), dtype=torch.float32, device=pts.device)
+    res = {}
+    tree = None
+    for name in ("build", "curve"):
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if name == "build":
+                if tree is not None:
+                    tree.close()
+                tree = T.KDTree.new_segments(pts, seg, nseg, ctx)
+            else:
+                tree.curvature_dev(K, F32_MAX, ctx, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        res[name] = min(ts[1:])
+    tree.close()
+    return {
+        "workload": f"{n} points in {nseg} segments (ground + trees), k={K}, r=f32::MAX, neighbours inside the segment only",
+        "build_ms": round(res["build"], 3),
+        "knn_curve_ms": round(res["curve"], 3),
+        "Mpoints_per_s": round(n / ((res["build"] + res["curve"]) * 1e-3) / 1e6, 1),
     }
 
 

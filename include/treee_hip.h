@@ -75,6 +75,13 @@ int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, 
 /* kNN structure over the cloud an octree has already Morton-sorted (shares the sorted arrays
  * by reference count: one sort feeds both; either handle may be freed first) */
 int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_knn **out);
+/* One structure for a cloud that is cut into segments the way the reference holds it after segmentation
+ * (`segment: Vec<u32>` beside the points, treee/src/calculations.rs:97-118): every segment behaves as its own
+ * KDTree::new(&segment_points) (calculations.rs:329, 392-403) -- a self query only ever returns points of the
+ * query's segment.  d_segment[i] in [0, n_segments), n_segments <= 2^24.  The handle serves
+ * treee_knn_self_dev and treee_curvature_dev (k <= 32); position queries are refused (TREEE_ERR_UNSUPPORTED). */
+int32_t treee_knn_build_segments_dev(treee_ctx *ctx, const float *d_xyz_aos, const uint32_t *d_segment,
+                                     uint64_t n, uint32_t n_segments, treee_knn **out);
 int32_t treee_knn_free(treee_knn *t);
 int32_t treee_knn_len(const treee_knn *t, uint64_t *n_out);
 
@@ -112,6 +119,11 @@ int32_t treee_curvature(const float *xyz_aos, uint64_t n, uint32_t k, float max_
                         float *curve_out);
 int32_t treee_curvature_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
                             float *d_curve_out);
+/* the same loop run for every segment of a segmented cloud in one pass: curve_out[i] is what
+ * SegmentInformation::update(calc_curve = true) computes for point i inside its own segment
+ * (calculations.rs:328-373 called per segment, interactive/mod.rs:224-231) */
+int32_t treee_curvature_segments(const float *xyz_aos, const uint32_t *segment, uint64_t n,
+                                 uint32_t n_segments, uint32_t k, float max_dist_sq, float *curve_out);
 /* map_to_u32 (treee/src/calculations.rs:455-457) over a device array */
 int32_t treee_map_to_u32_dev(treee_ctx *ctx, const float *d_in, uint64_t n, uint32_t *d_out);
 

@@ -209,6 +209,75 @@ def test_curvature_tie_free_cloud_tight_tolerance(T, oracle):
     assert u.tolist()[:50] == [oracle.map_to_u32(v) for v in got[:50]]
 
 
+# ---------------------------------------------------------------- A5 as the reference calls it: one tree per segment
+def test_segmented_knn_equals_one_tree_per_segment(T, oracle):
+    import torch
+
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(60_000, plot=14.0)
+    seg = seg.astype(np.uint32)
+    nseg = int(seg.max()) + 2  # one id that no point uses
+    # small segments: fewer points than k, exactly one point, 64 and 65 points (bucket edges)
+    order = np.argsort(seg, kind="stable")
+    ids = np.unique(seg)
+    big = ids[np.argmax(np.bincount(seg)[ids])]
+    extra = np.nonzero(seg == big)[0]
+    seg[extra[:5]] = nseg  # 5 points
+    seg[extra[5:6]] = nseg + 1  # 1 point
+    seg[extra[6:70]] = nseg + 2  # 64 points
+    seg[extra[70:135]] = nseg + 3  # 65 points
+    nseg += 4
+    tree = T.KDTree.new_segments(torch.from_numpy(pts).cuda(), torch.from_numpy(seg.astype(np.int32)).cuda(), nseg)
+    assert len(tree) == len(pts)
+    for k, maxd in ((31, F32_MAX), (8, 0.04)):
+        d, i, c = tree.self_neighbors_dev(k, maxd)
+        d, i, c = d.cpu().numpy(), i.cpu().numpy().view(np.uint32), c.cpu().numpy()
+        for sg in np.unique(seg):
+            members = np.nonzero(seg == sg)[0]
+            sp = pts[members]
+            ref = oracle.KDTree(sp)
+            r_ent, r_cnt = ref.k_nearest_batch(sp, k, maxd)
+            g = np.zeros((len(sp), k), T.ENTRY_DTYPE)
+            g["distance"] = d[members]
+            gi = i[members]
+            valid = np.arange(k)[None, :] < c[members][:, None]
+            # returned indices are whole-cloud indices of points of the same segment
+            assert np.all(seg[gi[valid]] == sg)
+            local = np.searchsorted(members, gi[valid])
+            gl = np.zeros(gi.shape, np.uint64)
+            gl[valid] = local
+            g["index"] = gl
+            check_knn_contract(sp, sp, g, c[members], r_ent, r_cnt)
+    # position queries have no segment
+    with pytest.raises(T.TreeeError):
+        tree.k_nearest_dev(torch.from_numpy(pts[:10]).cuda(), 3)
+    tree.close()
+    with pytest.raises(T.TreeeError):
+        T.KDTree.new_segments(torch.from_numpy(pts).cuda(), torch.from_numpy(seg.astype(np.int32)).cuda(), nseg - 1)
+
+
+def test_segmented_curvature_vs_per_segment_oracle(T, oracle):
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(50_000, plot=13.0)
+    seg = seg.astype(np.uint32)
+    nseg = int(seg.max()) + 1
+    got = T.curvature_segments(pts, seg, nseg)
+    ref = np.zeros(len(pts), np.float32)
+    for sg in np.unique(seg):
+        m = seg == sg
+        ref[m] = oracle.curvature(pts[m], 31, F32_MAX, threads=4)
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.max(np.abs(got[~nan] - ref[~nan])) < 1e-4
+    assert np.mean(np.abs(got[~nan] - ref[~nan]) < 1e-5) > 0.999
+    # one segment == the unsegmented call, bit for bit
+    one = T.curvature_segments(pts, np.zeros(len(pts), np.uint32), 1)
+    whole = T.curvature(pts)
+    assert np.array_equal(one.view(np.uint32), whole.view(np.uint32))
+
+
 # ---------------------------------------------------------------- A6-A7 splat
 def default_camera(T, w, h):
     cam = T.Camera3D(w / h)
@@ -342,6 +411,39 @@ def test_full_size_15m_properties(T, oracle):
     g_ent, g_cnt = sub.k_nearest_batch(pts[:20_000], 31, F32_MAX)
     r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts[:20_000], 31, F32_MAX, threads=8)
     check_knn_contract(pts, pts[:20_000], g_ent, g_cnt, r_ent, r_cnt)
+
+
+def test_full_size_15m_segmented_properties(T, oracle):
+    """configs[2] the way the reference holds a segmented cloud: one logical KD-tree per tree (2 501 segments)."""
+    import torch
+
+    from treee_amd import synth
+
+    n = 15_000_000
+    d_pts, d_seg = synth.forest_cloud_torch(n, "cuda")
+    nseg = int(d_seg.max().item()) + 1
+    tree = T.KDTree.new_segments(d_pts, d_seg, nseg)
+    dist, index, counts = tree.self_neighbors_dev(31)
+    seg_count = torch.bincount(d_seg.long(), minlength=nseg)
+    want = torch.clamp(seg_count[d_seg.long()], max=31).to(counts.dtype)
+    assert torch.equal(counts, want)
+    valid = torch.arange(31, device="cuda")[None, :] < counts[:, None]
+    idx = index.long().clamp(min=0)
+    same = d_seg.long()[idx] == d_seg.long()[:, None]
+    assert bool((same | ~valid).all())  # a neighbour never comes from another segment
+    assert bool((dist[:, 0] == 0).all())
+    assert bool(((dist[:, 1:] >= dist[:, :-1]) | ~valid[:, 1:]).all())
+    # sampled segments against the restated KD-tree built from that segment alone
+    seg = d_seg.cpu().numpy()
+    for sg in (1, 977, nseg - 1):
+        members = np.nonzero(seg == sg)[0]
+        sp = d_pts[torch.from_numpy(members).cuda()].cpu().numpy()
+        r_ent, r_cnt = oracle.KDTree(sp).k_nearest_batch(sp, 31, F32_MAX, threads=8)
+        g = np.zeros((len(sp), 31), T.ENTRY_DTYPE)
+        g["distance"] = dist[torch.from_numpy(members).cuda()].cpu().numpy()
+        g["index"] = np.searchsorted(members, index[torch.from_numpy(members).cuda()].cpu().numpy().view(np.uint32))
+        check_knn_contract(sp, sp, g, counts[torch.from_numpy(members).cuda()].cpu().numpy(), r_ent, r_cnt)
+    tree.close()
 
 
 # ---------------------------------------------------------------- kNN edge cases (sorted-32 kernel paths)

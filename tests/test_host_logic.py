@@ -106,6 +106,22 @@ def _ghost_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def test_partition_segments_is_balanced_and_deterministic():
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    _, seg = synth.forest_cloud(200_000, plot=40.0)
+    counts = np.bincount(seg.astype(np.int64))
+    for world in (1, 2, 4, 8):
+        owner = D.partition_segments(counts, world)
+        assert owner.shape == counts.shape and owner.min() >= 0 and owner.max() < world
+        load = np.bincount(owner, weights=counts, minlength=world)
+        assert load.sum() == counts.sum()
+        # LPT bound: no rank exceeds the mean by more than the largest segment
+        assert load.max() <= counts.sum() / world + counts.max()
+        assert np.array_equal(owner, D.partition_segments(counts, world))
+
+
 def test_ghost_exchange_world2_gloo(tmp_path):
     from treee_amd import distributed as D
 

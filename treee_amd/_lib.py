@@ -51,6 +51,7 @@ SYMBOLS = {
     "treee_knn_build": (_i32, [_vp, _u64, _pp]),
     "treee_knn_build_dev": (_i32, [_vp, _vp, _u64, _pp]),
     "treee_knn_from_octree_dev": (_i32, [_vp, _vp, _pp]),
+    "treee_knn_build_segments_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, C.POINTER(_vp)]),
     "treee_knn_free": (_i32, [_vp]),
     "treee_knn_len": (_i32, [_vp, C.POINTER(_u64)]),
     "treee_knn_query_batch": (_i32, [_vp, _vp, _u64, _u32, _f32, _vp, _vp]),
@@ -59,6 +60,7 @@ SYMBOLS = {
     "treee_knn_radius": (_i32, [_vp, _vp, _f32, _vp, _u64, C.POINTER(_u64)]),
     "treee_knn_empty": (_i32, [_vp, _vp, _u64, _f32, _vp]),
     "treee_curvature": (_i32, [_vp, _u64, _u32, _f32, _vp]),
+    "treee_curvature_segments": (_i32, [_vp, _vp, _u64, _u32, _u32, _f32, _vp]),
     "treee_curvature_dev": (_i32, [_vp, _vp, _u32, _f32, _vp]),
     "treee_map_to_u32_dev": (_i32, [_vp, _vp, _u64, _vp]),
     "treee_sort_build": (_i32, [_vp, _u64, _vp, _f32, _u32, _u32, _pp]),

@@ -24,6 +24,23 @@ def curvature(points, k=NEIGHBORS_COUNT, max_distance=NEIGHBORS_MAX_DISTANCE, ct
     return out
 
 
+def curvature_segments(points, segment, n_segments, k=NEIGHBORS_COUNT, max_distance=NEIGHBORS_MAX_DISTANCE, ctx=None):
+    """`curve` of every point inside its own segment: SegmentInformation::update(calc_curve=true) for all
+    segments in one pass (calculations.rs:328-373 per segment, interactive/mod.rs:224-231)."""
+    if is_device(points):
+        tree = KDTree.new_segments(points, segment, n_segments, ctx)
+        out = tree.curvature_dev(k, max_distance, ctx)
+        tree.ctx.sync()
+        tree.close()
+        return out
+    p = host_f32(points, 3)
+    sg = np.ascontiguousarray(segment, dtype=np.uint32)
+    assert len(sg) == len(p)
+    out = np.zeros(len(p), np.float32)
+    _lib.check(_lib.lib().treee_curvature_segments(ptr(p), ptr(sg), len(p), int(n_segments), k, max_distance, ptr(out)))
+    return out
+
+
 def map_to_u32_dev(values, ctx=None):
     """map_to_u32 over a device tensor: (value * u32::MAX as f32) as u32 (saturating)."""
     import torch

@@ -27,7 +27,9 @@ struct treee_knn {
 	std::shared_ptr<SortedCloud> sc = std::make_shared<SortedCloud>();
 	uint32_t nb = 0;       // buckets of 64 points
 	uint32_t P = 1;        // leaves padded to a power of two; node i: children 2i, 2i+1; leaf b = P + b
-	float4 *d_bvh = nullptr; // [2P][2] : (min.xyz,0), (max.xyz,0)
+	float4 *d_bvh = nullptr; // [2P][2] : (min.xyz, min segment), (max.xyz, max segment); segments are 0 unless `segmented`
+	bool segmented = false;  // buckets never straddle a segment; a query only sees its own segment (build_segmented)
+	uint64_t n_points = 0;   // points the handle was built from (sc->n counts the padding of a segmented handle too)
 	uint32_t *d_order = nullptr; // workgroup -> bucket of the self-query kernel (build_bvh), ~0u = padding
 	uint32_t n_order = 0;        // its length (8 * the longest XCD segment)
 	int device = 0;
@@ -40,7 +42,7 @@ constexpr int BUCKET = 64;
 
 // ---- bucket AABBs and the implicit tree ---------------------------------------------------------
 __global__ __launch_bounds__(256) void k_leaf_aabb(const float4 *__restrict__ pts, uint32_t n, uint32_t nb, uint32_t P,
-                                                    float4 *__restrict__ bvh) {
+                                                    const uint32_t *__restrict__ bucket_seg /* or null */, float4 *__restrict__ bvh) {
 	const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
 	if (b >= P) return;
 	const int lane = threadIdx.x & 63;
@@ -67,8 +69,16 @@ __global__ __launch_bounds__(256) void k_leaf_aabb(const float4 *__restrict__ pt
 			mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
 		}
 	if (lane == 0) {
-		bvh[2ull * (P + b) + 0] = make_float4(mn[0], mn[1], mn[2], 0.0f);
-		bvh[2ull * (P + b) + 1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+		// .w = segment range of the node (uint bits): [s, s] for a bucket of segment s, the empty range [~0, 0]
+		// for an unused leaf, [0, 0] everywhere when the cloud is not segmented
+		uint32_t slo = 0u, shi = 0u;
+		if (bucket_seg) {
+			const uint32_t sg = b < nb ? bucket_seg[b] : ~0u;
+			slo = sg;
+			shi = sg == ~0u ? 0u : sg;
+		}
+		bvh[2ull * (P + b) + 0] = make_float4(mn[0], mn[1], mn[2], __uint_as_float(slo));
+		bvh[2ull * (P + b) + 1] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(shi));
 	}
 }
 
@@ -77,8 +87,9 @@ __global__ __launch_bounds__(256) void k_inner_aabb(float4 *__restrict__ bvh, ui
 	if (t >= count) return;
 	const uint32_t i = first + t;
 	const float4 a0 = bvh[4ull * i + 0], a1 = bvh[4ull * i + 1], b0 = bvh[4ull * i + 2], b1 = bvh[4ull * i + 3];
-	bvh[2ull * i + 0] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), 0.0f);
-	bvh[2ull * i + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), 0.0f);
+	const uint32_t slo = min(__float_as_uint(a0.w), __float_as_uint(b0.w)), shi = max(__float_as_uint(a1.w), __float_as_uint(b1.w));
+	bvh[2ull * i + 0] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), __uint_as_float(slo));
+	bvh[2ull * i + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), __uint_as_float(shi));
 }
 
 // ---- per-lane top-k: binary max-heap in LDS, total order (distance bits, sorted position) ------
@@ -426,7 +437,10 @@ constexpr int FRONT_CAP = TREEE_FRONT_CAP; // BFS frontier; the default aliases 
 			x;                 \
 		}                      \
 	} while (0)
-template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a) {
+// SEG: the cloud is segmented (build_segmented) -- records are padded with (NaN, NaN, NaN, ~0u) so that no bucket
+// straddles a segment, tree nodes carry the range of segments below them, and a query only descends into / scans
+// nodes and buckets of its own segment: the result is what one KD-tree per segment returns (calculations.rs:329).
+template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a) {
 	__shared__ __attribute__((aligned(16))) float tile[3][BUCKET]; // SoA candidate tile (x[], y[], z[])
 	__shared__ uint32_t buf[2 * SBUF * 64]; // [pos | distance bits][slot][lane]: conflict-free per slot
 	__shared__ uint32_t s_list[LIST_CAP];
@@ -442,7 +456,7 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 	const uint32_t wave_id = (!a.q_xyz && a.wave_order) ? a.wave_order[blockIdx.x] : blockIdx.x;
 	if (wave_id == ~0u) return;
 	const uint32_t slot = wave_id * 64u + lane;
-	const bool live = slot < a.nq;
+	bool live = slot < a.nq;
 	float qx = 0.0f, qy = 0.0f, qz = 0.0f;
 	uint32_t row = 0, start;
 	if (a.q_xyz) {
@@ -460,8 +474,12 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 			qy = p.y;
 			qz = p.z;
 			row = __float_as_uint(p.w);
+			if constexpr (SEG) live = row != ~0u; // padding record
 		}
 		start = wave_id;
+	}
+	if constexpr (SEG) {
+		if (!__any(live)) return; // a bucket of padding only (the tail of the padded array)
 	}
 	// dead lanes never pass the filter: NaN query -> NaN distance
 	if (!live) qx = __uint_as_float(0x7FC00000u);
@@ -561,6 +579,8 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 	};
 
 	if (start >= a.nb) start = a.nb - 1;
+	uint32_t myseg = 0u; // wave-uniform: a bucket belongs to one segment
+	if constexpr (SEG) myseg = __float_as_uint(a.bvh[2ull * (a.P + start)].w);
 	// Own bucket, then its two neighbours in Morton order.  When a bucket straddles a jump of the
 	// curve, the lanes on its minority side find their real neighbours in the adjacent bucket; without
 	// it their threshold (and with it the wave's candidate list) would be enormous.
@@ -568,6 +588,9 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 	for (int t = 0; t < 3; ++t) {
 		const uint32_t b = t == 0 ? start : (t == 1 ? start - 1u : start + 1u); // start-1 wraps to a huge value at 0
 		if (b >= a.nb) continue;
+		if constexpr (SEG) {
+			if (t > 0 && __float_as_uint(a.bvh[2ull * (a.P + b)].w) != myseg) continue; // Morton neighbour of another segment
+		}
 		stage(load_bucket(b));
 		const uint32_t base = b * BUCKET;
 		int first = 0;
@@ -666,6 +689,7 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 				hit = hit || (__float_as_uint(bd) <= __float_as_uint(blo.w));
 			}
 			hit = hit && valid;
+			if constexpr (SEG) hit = hit && myseg >= __float_as_uint(lo.w) && myseg <= __float_as_uint(hi.w);
 			// the own bucket's Morton neighbours were scanned above (the own bucket is no seed's descendant)
 			const bool leafhit = hit && node >= a.P && (node - a.P) < a.nb && node - a.P != start - 1u && node - a.P != start + 1u;
 			const bool innerhit = hit && node < a.P;
@@ -819,7 +843,8 @@ template <bool DIAG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_kn
 			uint32_t i = root;
 			for (;;) {
 				const float4 lo = a.bvh[2ull * i + 0], hi = a.bvh[2ull * i + 1];
-				const bool hit = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) != 0;
+				bool hit = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) != 0;
+				if constexpr (SEG) hit = hit && myseg >= __float_as_uint(lo.w) && myseg <= __float_as_uint(hi.w);
 				ST(st_nodes++);
 				if (hit && i < a.P) {
 					i = 2u * i;
@@ -965,6 +990,7 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	if (k == 0) return set_err(TREEE_ERR_INVALID, "k == 0 (the reference panics at best_set.rs:74)");
 	if (nq == 0) return TREEE_OK;
 	if (nq >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "nq too large");
+	if (t->segmented && d_q) return set_err(TREEE_ERR_UNSUPPORTED, "segmented handle: only self queries (a position has no segment)");
 	const size_t lds = (size_t)k * 64 * 8 + 64 * 16;
 	if (lds > 160 * 1024) return set_err(TREEE_ERR_UNSUPPORTED, "k=%u exceeds the LDS-resident limit (319)", k);
 	KnnArgs a;
@@ -989,7 +1015,7 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	a.thr_io = nullptr;
 	a.thr_seed = 0;
 	static const bool want_stats = getenv("TREEE_KNN_STATS") != nullptr; // diagnostic counters
-	if (want_stats) {
+	if (want_stats && !t->segmented) {
 		TREEE_TRY(ctx->alloc_t(64, &a.stats));
 		TREEE_HIP(hipMemsetAsync(a.stats, 0, 256, ctx->stream));
 	}
@@ -1011,11 +1037,14 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	static const bool force_heap = getenv("TREEE_KNN_FORCE_HEAP") != nullptr; // A/B and test hook
 	if (k <= (uint32_t)SK && !force_heap) {
 		if (a.wave_order && !d_q) nwaves = t->n_order; // padded dispatch table
-		if (a.stats)
-			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+		if (t->segmented)
+			hipLaunchKernelGGL((k_knn_sorted32<false, true>), dim3(nwaves), dim3(64), 0, ctx->stream, a);
+		else if (a.stats)
+			hipLaunchKernelGGL((k_knn_sorted32<true, false>), dim3(nwaves), dim3(64), 0, ctx->stream, a);
 		else
-			hipLaunchKernelGGL(k_knn_sorted32<false>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+			hipLaunchKernelGGL((k_knn_sorted32<false, false>), dim3(nwaves), dim3(64), 0, ctx->stream, a);
 	} else {
+		if (t->segmented) return set_err(TREEE_ERR_UNSUPPORTED, "segmented handle: k=%u > 32 is not supported", k);
 		a.wave_order = nullptr;
 		if (lds > 64 * 1024)
 			TREEE_HIP(hipFuncSetAttribute((const void *)k_knn_heap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1036,10 +1065,10 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		static const bool want_ideal = getenv("TREEE_KNN_IDEAL") != nullptr;
 		if (want_ideal && k <= (uint32_t)SK && !d_q) { // lower bound: rerun with every threshold seeded by its final value
 			TREEE_TRY(ctx->alloc_t(nq, &a.thr_io));
-			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+			hipLaunchKernelGGL((k_knn_sorted32<true, false>), dim3(nwaves), dim3(64), 0, ctx->stream, a);
 			a.thr_seed = 1;
 			TREEE_HIP(hipMemsetAsync(a.stats, 0, 256, ctx->stream));
-			hipLaunchKernelGGL(k_knn_sorted32<true>, dim3(nwaves), dim3(64), 0, ctx->stream, a);
+			hipLaunchKernelGGL((k_knn_sorted32<true, false>), dim3(nwaves), dim3(64), 0, ctx->stream, a);
 			TREEE_HIP(hipMemcpyAsync(h, a.stats, 256, hipMemcpyDeviceToHost, ctx->stream));
 			TREEE_HIP(hipStreamSynchronize(ctx->stream));
 			fprintf(stderr, "[treee knn IDEAL] waves=%u buckets/wave=%.2f flushes/wave=%.2f nodes/wave=%.2f\n", h[3], h[0] / (double)h[3], h[1] / (double)h[3], h[2] / (double)h[3]);
@@ -1079,14 +1108,64 @@ __global__ __launch_bounds__(256) void k_order_interleave(const uint32_t *__rest
 	table[p] = slot < order_count(nb, x) ? sorted[start + slot] : ~0u;
 }
 
-int32_t build_bvh(treee_ctx *ctx, treee_knn *t) {
+
+// ---- segmented clouds: one logical KD-tree per segment (calculations.rs:97-118,329) in one structure ----------
+// segment id of every point in Morton order; ids outside [0, nseg) raise the error flag
+__global__ __launch_bounds__(256) void k_seg_gather(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ perm, uint32_t n, uint32_t nseg,
+                                                     uint32_t *__restrict__ out, uint32_t *__restrict__ err) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	uint32_t sg = seg[perm[i]];
+	if (sg >= nseg) {
+		atomicOr(err, 1u);
+		sg = nseg - 1u;
+	}
+	out[i] = sg;
+}
+
+// start[s] = first position of segment s in the (segment, Morton)-sorted order, start[nseg] = n;
+// nb[s] = its number of 64-point buckets
+__global__ __launch_bounds__(256) void k_seg_starts(const uint32_t *__restrict__ sorted_seg, uint32_t n, uint32_t nseg, uint32_t *__restrict__ start) {
+	const uint32_t sg = blockIdx.x * 256u + threadIdx.x;
+	if (sg > nseg) return;
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) { // first position with segment >= sg
+		const uint32_t mid = lo + ((hi - lo) >> 1);
+		if (sorted_seg[mid] < sg)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	start[sg] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_seg_buckets(const uint32_t *__restrict__ start, uint32_t nseg, uint32_t *__restrict__ nb) {
+	const uint32_t sg = blockIdx.x * 256u + threadIdx.x;
+	if (sg >= nseg) return;
+	nb[sg] = (start[sg + 1] - start[sg] + 63u) / 64u;
+}
+
+// records into the padded layout: segment s owns buckets [base[s], base[s] + nb[s]); unused slots keep the
+// (NaN, NaN, NaN, ~0u) fill
+__global__ __launch_bounds__(256) void k_seg_scatter(const float *__restrict__ xyz, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ sorted_seg,
+                                                      const uint32_t *__restrict__ start, const uint32_t *__restrict__ base, uint32_t n,
+                                                      float4 *__restrict__ rec, uint32_t *__restrict__ bucket_seg) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t sg = sorted_seg[i], o = perm[i];
+	const uint32_t dst = base[sg] * 64u + (i - start[sg]);
+	rec[dst] = make_float4(xyz[3ull * o + 0], xyz[3ull * o + 1], xyz[3ull * o + 2], __uint_as_float(o));
+	if ((dst & 63u) == 0u) bucket_seg[dst >> 6] = sg;
+}
+
+int32_t build_bvh(treee_ctx *ctx, treee_knn *t, const uint32_t *d_bucket_seg = nullptr) {
 	const uint64_t n = t->sc->n;
 	t->nb = div_up(n, BUCKET);
 	t->P = 1;
 	while (t->P < t->nb) t->P <<= 1;
 	t->owner = ctx;
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->P * 2 * 2, &t->d_bvh));
-	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 4)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, t->d_bvh);
+	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 4)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, d_bucket_seg, t->d_bvh);
 	for (uint32_t lvl = t->P >> 1; lvl >= 1; lvl >>= 1) // nodes [lvl, 2*lvl)
 		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
 	TREEE_LAUNCH_CHECK();
@@ -1108,9 +1187,107 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t) {
 	return TREEE_OK;
 }
 
+
+// Sorted by (segment, Morton key, original index): a 30-bit Morton sort followed by a stable sort on the segment id.
+int32_t build_segmented(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_seg, uint64_t n, uint32_t nseg, treee_knn *t) {
+	if (n >= (1ull << 31) - 64ull * nseg) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per shard", (unsigned long long)n);
+	SortedCloud *sc = t->sc.get();
+	sc->device = ctx->device;
+	sc->owner = ctx;
+	t->owner = ctx;
+	t->segmented = true;
+	t->n_points = n;
+	TREEE_TRY(bbox_dev(ctx, d_xyz, n, sc->corner, &sc->size));
+	const uint64_t nb_max = div_up(n, 64) + nseg; // sum over segments of ceil(count / 64) <= n / 64 + nseg
+	sc->n = nb_max * 64;
+	TREEE_TRY(pool_alloc_t(ctx, sc->n, &sc->d_sorted));
+	uint32_t *d_keys_raw = nullptr, *d_keys = nullptr, *d_perm = nullptr, *d_sk = nullptr, *d_sks = nullptr, *d_perm2 = nullptr;
+	uint32_t *d_start = nullptr, *d_nb = nullptr, *d_base = nullptr, *d_bseg = nullptr, *d_err = nullptr;
+	TREEE_TRY(ctx->alloc_t(n, &d_keys_raw));
+	TREEE_TRY(ctx->alloc_t(n, &d_keys));
+	TREEE_TRY(ctx->alloc_t(n, &d_perm));
+	TREEE_TRY(ctx->alloc_t(n, &d_sk));
+	TREEE_TRY(ctx->alloc_t(n, &d_sks));
+	TREEE_TRY(ctx->alloc_t(n, &d_perm2));
+	TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_start));
+	TREEE_TRY(ctx->alloc_t(nseg, &d_nb));
+	TREEE_TRY(ctx->alloc_t(nseg, &d_base));
+	TREEE_TRY(ctx->alloc_t(nb_max, &d_bseg));
+	TREEE_TRY(ctx->alloc_t(1, &d_err));
+	hipStream_t st = ctx->stream;
+	TREEE_HIP(hipMemsetAsync(d_err, 0, 4, st));
+	TREEE_HIP(hipMemsetAsync(sc->d_sorted, 0xFF, sc->n * sizeof(float4), st)); // (NaN, NaN, NaN, ~0u)
+	TREEE_HIP(hipMemsetAsync(d_bseg, 0xFF, nb_max * 4, st));
+	TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
+	TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, d_keys, d_perm));
+	hipLaunchKernelGGL(k_seg_gather, dim3(div_up(n, 256)), dim3(256), 0, st, d_seg, d_perm, (uint32_t)n, nseg, d_sk, d_err);
+	TREEE_LAUNCH_CHECK();
+	int bits = 1;
+	while (bits < 32 && (1ull << bits) < nseg) ++bits;
+	TREEE_TRY(sort_pairs_dev(ctx, d_sk, d_perm, n, bits, d_sks, d_perm2));
+	hipLaunchKernelGGL(k_seg_starts, dim3(div_up((uint64_t)nseg + 1, 256)), dim3(256), 0, st, d_sks, (uint32_t)n, nseg, d_start);
+	hipLaunchKernelGGL(k_seg_buckets, dim3(div_up(nseg, 256)), dim3(256), 0, st, d_start, nseg, d_nb);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_nb, d_base, nseg, nullptr));
+	hipLaunchKernelGGL(k_seg_scatter, dim3(div_up(n, 256)), dim3(256), 0, st, d_xyz, d_perm2, d_sks, d_start, d_base, (uint32_t)n, sc->d_sorted, d_bseg);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(build_bvh(ctx, t, d_bseg));
+	uint32_t err = 0;
+	TREEE_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipStreamSynchronize(st));
+	if (err) return set_err(TREEE_ERR_INVALID, "segment id >= n_segments (%u)", nseg);
+	return TREEE_OK;
+}
+
 } // namespace
 
 extern "C" {
+
+int32_t treee_knn_build_segments_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_segment, uint64_t n, uint32_t n_segments, treee_knn **out) {
+	if (!ctx || !out) return set_err(TREEE_ERR_INVALID, "treee_knn_build_segments_dev: null argument");
+	*out = nullptr;
+	if (n == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");
+	if (!d_xyz || !d_segment) return set_err(TREEE_ERR_INVALID, "treee_knn_build_segments_dev: null array");
+	if (n_segments == 0 || n_segments > (1u << 24)) return set_err(TREEE_ERR_INVALID, "n_segments %u outside [1, 2^24]", n_segments);
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	treee_knn *t = new treee_knn;
+	t->device = ctx->device;
+	const int32_t rc = build_segmented(ctx, d_xyz, d_segment, n, n_segments, t);
+	if (rc != TREEE_OK) {
+		treee_knn_free(t);
+		return rc;
+	}
+	*out = t;
+	return TREEE_OK;
+}
+
+int32_t treee_curvature_segments(const float *xyz, const uint32_t *segment, uint64_t n, uint32_t n_segments, uint32_t k, float max_dist_sq,
+                                 float *curve_out) {
+	if (n == 0) return TREEE_OK;
+	if (!xyz || !segment || !curve_out) return set_err(TREEE_ERR_INVALID, "treee_curvature_segments: null argument");
+	if (k == 0) return set_err(TREEE_ERR_INVALID, "k == 0");
+	treee_ctx *ctx = nullptr;
+	TREEE_DEFAULT_CTX(ctx);
+	TREEE_HIP(hipSetDevice(ctx->device));
+	DevBuf<float> d_xyz, d_curve;
+	DevBuf<uint32_t> d_seg;
+	TREEE_TRY(d_xyz.alloc(n * 3));
+	TREEE_TRY(d_seg.alloc(n));
+	TREEE_TRY(d_curve.alloc(n));
+	TREEE_HIP(hipMemcpyAsync(d_xyz.p, xyz, n * 12, hipMemcpyHostToDevice, ctx->stream));
+	TREEE_HIP(hipMemcpyAsync(d_seg.p, segment, n * 4, hipMemcpyHostToDevice, ctx->stream));
+	treee_knn *t = nullptr;
+	TREEE_TRY(treee_knn_build_segments_dev(ctx, d_xyz.p, d_seg.p, n, n_segments, &t));
+	int32_t rc = treee_curvature_dev(ctx, t, k, max_dist_sq, d_curve.p);
+	if (rc == TREEE_OK) {
+		hipError_t e = hipMemcpyAsync(curve_out, d_curve.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e != hipSuccess) rc = set_err(TREEE_ERR_HIP, "curvature copy back: %s", hipGetErrorString(e));
+	}
+	treee_knn_free(t);
+	return rc;
+}
 
 int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, treee_knn **out) {
 	if (!ctx || !out) return set_err(TREEE_ERR_INVALID, "treee_knn_build_dev: null argument");
@@ -1121,6 +1298,7 @@ int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, tree
 	TREEE_TRY(ctx->reset());
 	treee_knn *t = new treee_knn;
 	t->device = ctx->device;
+	t->n_points = n;
 	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, nullptr, 0.0f, t->sc.get());
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);
@@ -1144,6 +1322,7 @@ int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_k
 	treee_knn *t = new treee_knn;
 	t->device = ctx->device;
 	t->sc = sc; // one Morton sort, two consumers
+	t->n_points = sc->n;
 	int32_t rc = build_bvh(ctx, t);
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);
@@ -1181,7 +1360,7 @@ int32_t treee_knn_free(treee_knn *t) {
 
 int32_t treee_knn_len(const treee_knn *t, uint64_t *n_out) {
 	if (!t || !n_out) return set_err(TREEE_ERR_INVALID, "treee_knn_len: null argument");
-	*n_out = t->sc->n;
+	*n_out = t->n_points;
 	return TREEE_OK;
 }
 
@@ -1325,6 +1504,7 @@ __global__ __launch_bounds__(256) void k_radius_emit(const uint32_t *__restrict_
 extern "C" int32_t treee_knn_radius(const treee_knn *t, const float q[3], float max_dist_sq, treee_entry *out, uint64_t cap,
                                     uint64_t *found_out) {
 	if (!t || !q || !found_out || (cap && !out)) return set_err(TREEE_ERR_INVALID, "treee_knn_radius: null argument");
+	if (t->segmented) return set_err(TREEE_ERR_UNSUPPORTED, "segmented handle: only self queries (a position has no segment)");
 	treee_ctx *ctx = nullptr;
 	TREEE_DEFAULT_CTX(ctx);
 	TREEE_HIP(hipSetDevice(ctx->device));

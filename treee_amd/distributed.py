@@ -174,3 +174,20 @@ def reduce_packed_min(packed, group=None):
     """element-wise MIN of the packed (depth_bits << 32 | index) frame buffers of all ranks.
     depth < 1.0 keeps the sign bit clear, so the signed int64 order equals the unsigned one."""
     return _all_reduce(packed, dist.ReduceOp.MIN, group)
+
+
+def partition_segments(counts, world):
+    """SURVEY 8 E, first form: the reference's kNN units are whole segments (one KD-tree per segment,
+    calculations.rs:97-118), so they shard with no exchange at all.  Greedy longest-processing-time assignment of
+    segments to ranks by point count; deterministic (ties: lower segment id first, lower rank first).
+    Returns owner[n_segments] (int64 numpy)."""
+    import numpy as np
+
+    counts = np.asarray(counts, dtype=np.int64)
+    owner = np.zeros(len(counts), np.int64)
+    load = np.zeros(world, np.int64)
+    for sg in np.lexsort((np.arange(len(counts)), -counts)):
+        r = int(np.argmin(load))
+        owner[sg] = r
+        load[r] += counts[sg]
+    return owner

@@ -44,6 +44,24 @@ class KDTree:
         return self
 
     @classmethod
+    def new_segments(cls, points, segment, n_segments, ctx=None):
+        """One structure that behaves as `KDTree::new(&segment_points)` per segment (calculations.rs:97-118,329):
+        `segment` is the u32 id of every point (the `segment: Vec<u32>` array the reference keeps beside the
+        points), ids in [0, n_segments).  Device tensors only; serves self_neighbors_dev / curvature_dev."""
+        import torch
+
+        self = object.__new__(cls)
+        self.ctx = ctx or default_context(points.device)
+        p = dev_f32(points, 3)
+        sg = segment.to(torch.int32).contiguous()
+        assert sg.shape[0] == p.shape[0] and sg.device == p.device
+        self.n = p.shape[0]
+        h = C.c_void_p()
+        _lib.check(_lib.lib().treee_knn_build_segments_dev(self.ctx.handle, ptr(p), ptr(sg), self.n, int(n_segments), C.byref(h)))
+        self._h, self.device = h, p.device
+        return self
+
+    @classmethod
     def from_octree(cls, octree, ctx=None):
         """kNN structure over the cloud `octree` has already Morton-sorted (no second sort)."""
         self = object.__new__(cls)
