@@ -234,6 +234,7 @@ def main():
             out["hbm_copy_GBps"] = measured_copy_gbps(dev)
             out["ingest"] = ingest_stage(n, dev, ctx)
             out["per_segment_knn"] = segment_stage(pts, seg, ctx)
+            out["out_of_core"] = out_of_core_stage(dev, n, proj)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -334,6 +335,41 @@ def segment_stage(pts, seg, ctx):
         "knn_curve_ms": round(res["curve"], 3),
         "Mpoints_per_s": round(n / ((res["build"] + res["curve"]) * 1e-3) / 1e6, 1),
     }
+
+
+def out_of_core_stage(dev, n, proj, tiles=67):
+    """BASELINE.json configs[4] on one GPU: 67 forest tiles = 1.005 G points streamed from pinned host memory as
+    uncompressed LAS format-0 records (20 B) through decode -> Morton sort -> octree/LOD -> splat (and, second line,
+    with kNN k=31 + curvature per tile), PCIe copies overlapped with compute on a second stream
+    (treee_amd/stream.py).  PCIe-inclusive; beside the step, not part of `value`."""
+    import treee_amd as T
+    from treee_amd import stream, synth
+
+    base = []
+    for i in range(3):
+        p, _ = synth.forest_cloud_torch(n, dev, plot=PLOT, seed=synth.SEED_FOREST + 100 + i)
+        base.append(stream.las_tile_from_cloud(p))
+        del p
+    view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 100.0 + 0.9 * 9 * PLOT))
+    env = T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+
+    def gen(count):
+        for i in range(count):
+            b = base[i % len(base)]  # placed on a 9 x 8 grid through the LAS header offset
+            yield stream.Tile(b.records, b.n, b.stride, b.scale, ((i % 9) * PLOT, (i // 9) * PLOT, 0.0), (4 * PLOT, 3.5 * PLOT, 0.0))
+
+    res = {"workload": f"{tiles} LAS tiles x {n} points from pinned host memory, 20 B records"}
+    for name, k in (("octree_splat", 0), ("octree_knn_splat", K)):
+        ts = stream.TileStream(dev, n, width=W, height=H, knn_k=k)
+        ts.run(gen(3), view, proj, env)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = ts.run(gen(tiles), view, proj, env)
+        dt = time.perf_counter() - t0
+        ts.close()
+        res[name] = {"points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1),
+                     "pcie_GBps": round(r["points"] * 20 / dt / 1e9, 1)}
+    return res
 
 
 def measured_traffic(points):

@@ -446,6 +446,57 @@ def test_full_size_15m_segmented_properties(T, oracle):
     tree.close()
 
 
+# ---------------------------------------------------------------- configs[4]: out-of-core tile stream
+@pytest.mark.parametrize("knn_k", [0, 31])
+def test_tile_stream_equals_tile_by_tile(T, oracle, knn_k):
+    """Two streams + double buffering must not change a bit: same octrees, same frame as the plain sequence
+    decode -> octree -> [curvature] -> accumulate-splat run tile after tile on one stream; first tile's decode and
+    frame also against the oracle."""
+    import torch
+
+    from treee_amd import laz, stream, synth
+
+    w, h = 320, 200
+    tiles = []
+    for i, n in enumerate((70_001, 50_000, 64)):
+        pts, _ = synth.forest_cloud_torch(n, "cuda", plot=15.0, seed=synth.SEED_FOREST + i)
+        t = stream.las_tile_from_cloud(pts)
+        tiles.append(stream.Tile(t.records, t.n, t.stride, t.scale, (i * 15.0, 0.0, 0.0), (15.0, 0.0, 5.0)))
+    cam = T.Camera3D(w / h)
+    proj = cam.projection()
+    view = T.view_from_transform(T.rotation_x(-0.5) @ T.translation(0.0, 0.0, 60.0))
+    env = T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+    ts = stream.TileStream("cuda:0", 80_000, width=w, height=h, knn_k=knn_k)
+    seen = []
+    res = ts.run(tiles, view, proj, env, on_tile=lambda i, tile, oc, xyz: seen.append((oc.array("nodes"), xyz.clone())))
+    got = ts.packed.clone()
+    ts.close()
+    assert res["points"] == sum(t.n for t in tiles)
+    # the plain sequence
+    ctx = T.default_context(torch.device("cuda", 0))
+    packed = torch.empty((h, w), dtype=torch.int64, device="cuda")
+    base = 0
+    for i, t in enumerate(tiles):
+        xyz = laz.Chunk(t.records.cuda(), t.stride, t.offset, t.scale, t.center).read(ctx)
+        assert torch.equal(xyz, seen[i][1])
+        oc = T.Octree(xyz, ctx=ctx)
+        assert np.array_equal(oc.array("nodes"), seen[i][0])
+        assert res["tiles"][i]["nodes"] == oc.n_nodes and res["tiles"][i]["lod"] == oc.n_lod
+        if knn_k:
+            val = T.map_to_u32_dev(T.KDTree.from_octree(oc, ctx).curvature_dev(knn_k, F32_MAX, ctx), ctx)
+        else:
+            val = torch.zeros((t.n,), dtype=torch.int32, device="cuda")
+        T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(xyz), T.context.ptr(val), t.n, T.context.ptr(view), T.context.ptr(proj),
+                                             env.scale, env.min, env.max, w, h, T.context.ptr(packed), 1 if i else 0, base, None, None))
+        base += t.n
+        oc.close()
+    assert torch.equal(got, packed)
+    # oracle: decode of tile 0 and the frame of tile 0 alone
+    t0 = tiles[0]
+    ref_xyz = oracle.decode_las_records(t0.records.numpy().tobytes(), t0.n, t0.stride, list(t0.scale), list(t0.offset), list(t0.center))
+    assert np.array_equal(ref_xyz.view(np.uint32), seen[0][1].cpu().numpy().view(np.uint32))
+
+
 # ---------------------------------------------------------------- kNN edge cases (sorted-32 kernel paths)
 @pytest.mark.parametrize("k", [1, 2, 7, 16, 31, 32, 33])
 def test_knn_every_small_k(T, oracle, k):
