@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=15_000_000, help="points per GPU")
+    ap.add_argument("--plot", type=float, default=PLOT, help="edge of the square tile in metres (632 with --points 150000000 keeps the density)")
     ap.add_argument("--halo", type=float, default=2.0)
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="points of the CPU-baseline sample (about 10-30 s of oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,12 +94,13 @@ def main():
     T.lib()
     ctx = T.default_context(dev)
     n = args.points
-    origin = D.tile_origin(rank, world, PLOT)
-    bounds = D.tile_bounds(rank, world, PLOT)
-    pts, seg = synth.forest_cloud_torch(n, dev, plot=PLOT, seed=synth.SEED_FOREST + rank, origin=origin)
+    plot = args.plot
+    origin = D.tile_origin(rank, world, plot)
+    bounds = D.tile_bounds(rank, world, plot)
+    pts, seg = synth.forest_cloud_torch(n, dev, plot=plot, seed=synth.SEED_FOREST + rank, origin=origin)
     cam = T.Camera3D(W / H)
     proj = cam.projection()
-    span = PLOT * max(D.tile_grid(world))
+    span = plot * max(D.tile_grid(world))
     view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 100.0 + 0.9 * span))
     env = T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
     packed = torch.empty((H, W), dtype=torch.int64, device=dev)
@@ -209,7 +211,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"forest {n} pts/GPU on {PLOT:.0f}m tile: morton radix sort + octree/LOD + kNN k=31 r=f32::MAX + curvature + splat {W}x{H}",
+                "workload": f"forest {n} pts/GPU on {plot:.0f}m tile: morton radix sort + octree/LOD + kNN k=31 r=f32::MAX + curvature + splat {W}x{H}",
                 "points_per_gpu": n,
                 "k": K,
                 "framebuffer": [W, H],
@@ -230,7 +232,7 @@ def main():
             "stages": stage_roof,
             "end_to_end_GBps": round((sum(BYTES.values()) * n + 24 * W * H) / (elapsed / args.steps) / 1e9 * world, 1),
         }
-        if world == 1:
+        if world == 1 and n == 15_000_000:
             out["hbm_copy_GBps"] = measured_copy_gbps(dev)
             out["ingest"] = ingest_stage(n, dev, ctx)
             out["per_segment_knn"] = segment_stage(pts, seg, ctx)

@@ -500,7 +500,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 	constexpr uint32_t DB_OFS = SBUF * 64 * 4; // distance-bits plane behind the position plane
 	uint32_t st_buckets = 0, st_flush = 0, st_nodes = 0, st_need = 0, st_small = 0;
 	unsigned long long st_t0 = 0ull, st_tp = 0ull, st_tf = 0ull;
-	uint32_t st_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t st_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	ST(st_t0 = st_tp = __builtin_amdgcn_s_memtime());
 #define PH(i) ST(const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st_ph[i] += (uint32_t)(t__ - st_tp); st_tp = t__)
 
@@ -610,6 +610,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 			}
 			bitonic_sort<SK>(L);
 			thr = key_db(L[SK - 1]);
+			ST(if (a.thr_io && a.thr_seed && live) thr = min(thr, a.thr_io[slot]));
 			first = SK;
 		}
 		scan_tile(base, ~0ull, first);
@@ -746,11 +747,11 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 			// next listed bucket (index >= from) that some lane still needs, judged with the current
 			// threshold (it only ever shrinks, so a stale decision is merely conservative)
 			uint64_t need = 0; // queries that need the bucket find_next returned
-			auto find_next = [&](uint32_t from) __attribute__((always_inline)) -> uint32_t {
+			auto find_next = [&](uint32_t from, uint64_t &mask) __attribute__((always_inline)) -> uint32_t {
 				for (uint32_t j = from; j < gcount; ++j) {
 					const float4 lo = s_gbox[j][0], hi = s_gbox[j][1]; // same address in every lane: LDS broadcast
-					need = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
-					if (need) return j;
+					mask = lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+					if (mask) return j;
 				}
 				return gcount;
 			};
@@ -761,7 +762,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 				return a.pts + (i < a.n ? i : a.n - 1u);
 			};
 			PH(5);
-			uint32_t j = find_next(0);
+			uint32_t j = find_next(0, need);
 			PH(2);
 			// Prefetch of the next bucket's record.  A plain load would be sunk by hipcc to its first use
 			// (below the scan it should overlap); a wavefront-scope release fence costs no instruction
@@ -784,8 +785,8 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 				// order matters: consume this bucket's registers (LDS staging) BEFORE the next load is issued,
 				// otherwise the wait for `cand` also drains the prefetch and exposes its latency
 				if (!small) stage(cand);
-				PH(5);
-				j = find_next(j + 1);
+				PH(8);
+				j = find_next(j + 1, need);
 				if (j < gcount) issue_prefetch(j); // in flight during the scan below
 				PH(2);
 				uint64_t full = ~0ull; // queries to serve with the lane-parallel scan
@@ -875,6 +876,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 		atomicMax(&a.stats[7], cyc);
 		if (overflow) atomicAdd(&a.stats[8], 1u);
 		for (int i = 0; i < 7; ++i) atomicAdd(&a.stats[40 + i], st_ph[i] >> 10);
+		atomicAdd(&a.stats[50], st_ph[8] >> 10);
 		atomicAdd(&a.stats[47], st_ph[7]);
 		atomicMax(&a.stats[48], st_ph[7]);
 		atomicAdd(&a.stats[9 + (cyc >> 10 > 21 ? 21 : cyc >> 10)], 1u); // histogram, 65536-cycle bins
@@ -1055,8 +1057,8 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		uint32_t h[64];
 		TREEE_HIP(hipMemcpyAsync(h, a.stats, 256, hipMemcpyDeviceToHost, ctx->stream));
 		TREEE_HIP(hipStreamSynchronize(ctx->stream));
-		fprintf(stderr, "[treee knn phases] kcycles/wave: own+nbr=%.0f bfs=%.0f find_next=%.0f transposed=%.0f fullscan=%.0f other=%.0f | of which flushes=%.0f | listed buckets mean=%.1f max=%u\n", h[40] * 1.024 / h[3],
-		        h[41] * 1.024 / h[3], h[42] * 1.024 / h[3], h[43] * 1.024 / h[3], h[44] * 1.024 / h[3], h[45] * 1.024 / h[3], h[46] * 1.024 / h[3], h[47] / (double)h[3], h[48]);
+		fprintf(stderr, "[treee knn phases] kcycles/wave: own+nbr=%.0f bfs=%.0f find_next=%.0f transposed=%.0f fullscan=%.0f gbox=%.0f bucket-wait=%.0f | of which flushes=%.0f | listed buckets mean=%.1f max=%u\n", h[40] * 1.024 / h[3],
+		        h[41] * 1.024 / h[3], h[42] * 1.024 / h[3], h[43] * 1.024 / h[3], h[44] * 1.024 / h[3], h[45] * 1.024 / h[3], h[50] * 1.024 / h[3], h[46] * 1.024 / h[3], h[47] / (double)h[3], h[48]);
 		fprintf(stderr, "[treee knn cycles] mean=%.0f max=%.0f overflow-waves=%u hist(64k-cycle bins):", h[6] * 1024.0 / h[3], h[7] * 64.0, h[8]);
 		for (int i = 0; i < 22; ++i) fprintf(stderr, " %u", h[9 + i]);
 		fprintf(stderr, "\n");
