@@ -519,6 +519,21 @@ def test_knn_massive_duplicates_and_ties(T, oracle):
         check_knn_contract(pts, q, g_ent, g_cnt, r_ent, r_cnt)
 
 
+def test_knn_denormal_distances(T, oracle):
+    """squared distances in the f32-denormal range (and exact zeros): the per-lane keys are then zero / denormal
+    when the kernel orders them as doubles, which must not be flushed"""
+    rng = np.random.default_rng(5)
+    step = np.float32(2.0e-20)
+    grid = (rng.integers(0, 40, (4000, 3)).astype(np.float32) * step).astype(np.float32)  # d^2 ~ 4e-40 .. 2e-36
+    pts = np.concatenate([grid, grid[:300], (rng.random((1500, 3)) * 3).astype(np.float32)])
+    for maxd in (F32_MAX, 1.0e-37, 5.0e-39):
+        r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts[:3000], 31, maxd)
+        g_ent, g_cnt = T.KDTree.new(pts).k_nearest_batch(pts[:3000], 31, maxd)
+        check_knn_contract(pts, pts[:3000], g_ent, g_cnt, r_ent, r_cnt)
+    d = r_ent["distance"][:, 1:8]
+    assert np.any((d > 0) & (d < np.float32(1.1754944e-38)))  # the case is really exercised
+
+
 def test_knn_nan_inf_and_extreme_inputs(T, oracle):
     rng = np.random.default_rng(21)
     pts = (rng.random((5000, 3)) * 20).astype(np.float32)

@@ -359,12 +359,18 @@ constexpr int SCHUNK = TREEE_SCHUNK; // candidates scanned between flush checks 
 #define TREEE_TRANSPOSE_BELOW 20
 #endif
 constexpr int TRANSPOSE_BELOW = TREEE_TRANSPOSE_BELOW; // buckets needed by fewer queries are scanned transposed
-// Keys are (distance bits + KEY_BIAS) << 32 | sorted position.  Distances are >= +0, so the
-// biased high word lies in [0x00100000, 0x7F900000]: read as an IEEE double every key is a
-// positive NORMAL number, and for positive doubles the numeric order equals the unsigned order
-// of the bit patterns.  A compare-exchange is therefore v_min_f64 + v_max_f64 (2 VALU instead
-// of a 64-bit compare + 4 selects); min/max return one operand unchanged, so bits survive.
-constexpr uint32_t KEY_BIAS = 0x00100000u;
+// Keys are distance bits << 32 | sorted position.  Distances are >= +0 and at most +inf (0x7F800000), so read as
+// an IEEE double every key is a non-negative, non-NaN number (possibly zero or denormal), and for such doubles the
+// numeric order equals the unsigned order of the bit patterns.  A compare-exchange is therefore v_min_f64 +
+// v_max_f64 (2 VALU instead of a 64-bit compare + 4 selects); min/max return one operand unchanged, so bits
+// survive -- PROVIDED f64 denormals are not flushed: the code object keeps hipcc's default
+// FLOAT_DENORM_MODE_16_64 = 3 (only -fgpu-flush-denormals-to-zero for f32 exists as a switch), and
+// tests/test_gpu_parity.py::test_knn_denormal_distances pins it.  (An earlier version added 0x00100000 to the high
+// word to make every key a normal number: 1 VALU per key built or read, 4.5 % of the kernel.)
+#ifndef TREEE_KEY_BIAS
+#define TREEE_KEY_BIAS 0u
+#endif
+constexpr uint32_t KEY_BIAS = TREEE_KEY_BIAS;
 constexpr unsigned long long KEY_MAX = 0x7FEFFFFFFFFFFFFFull; // largest finite double > every key
 
 __device__ __forceinline__ double key_make(uint32_t db, uint32_t pos) {
