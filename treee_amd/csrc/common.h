@@ -145,6 +145,7 @@ struct SortedCloud {
 	uint32_t *d_perm = nullptr;  // sorted position -> original index
 	float4 *d_sorted = nullptr;  // (x,y,z,bitcast(orig)) sorted
 	int device = 0;
+	int crowded = -1; // some Morton cell holds more than LONG_RUN points: -1 unknown, else 0 / 1 (long_run_flag_dev)
 	treee_ctx *owner = nullptr; // context whose pool the arrays came from
 	SortedCloud() = default;
 	SortedCloud(const SortedCloud &) = delete;
@@ -156,6 +157,12 @@ struct SortedCloud {
 std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o);
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner,
                            float size, SortedCloud *out);
+// *d_flag (device, zeroed here) = 1 iff sorted keys hold a run of more than LONG_RUN equal keys
+#ifndef TREEE_LONG_RUN
+#define TREEE_LONG_RUN 256
+#endif
+constexpr uint32_t LONG_RUN = TREEE_LONG_RUN;
+int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_sorted_keys, uint64_t n, uint32_t *d_flag);
 
 // default context for the host-pointer API (created lazily, one per process)
 int32_t default_ctx(treee_ctx **out);

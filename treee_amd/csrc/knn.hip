@@ -1117,6 +1117,100 @@ __global__ __launch_bounds__(256) void k_order_interleave(const uint32_t *__rest
 }
 
 
+// ---- dense cells: a finer order inside Morton cells that hold many points -------------------------------------
+// The shared sort uses 10 bits per axis.  A cloud whose density varies by orders of magnitude (a scanner standing
+// next to a wall, a blob of returns) puts thousands of points into one cell; inside a cell the order is the
+// original index, so every bucket cut from it spans the whole cell and a query there has to scan them all.  When
+// a cell holds more than LONG_RUN points the kNN structure therefore re-sorts its own copy of the cloud by a
+// 20-bit-per-axis key (low 10 bits first, then stable by the existing key).  The octree keeps the 30-bit order.
+__device__ __forceinline__ uint32_t quant_lo10(float p, float c, float size) { // bits 9..0 of the 20-bit cell index
+	const float t = ((p - c) / size) * 1048576.0f; // same quotient as the 10-bit key, scaled by a power of two
+	if (!(t >= 0.0f)) return 0u;
+	if (t >= 1048576.0f) return 1023u;
+	return (uint32_t)t & 1023u;
+}
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+	v &= 0x3FFu;
+	v = (v | (v << 16)) & 0x030000FFu;
+	v = (v | (v << 8)) & 0x0300F00Fu;
+	v = (v | (v << 4)) & 0x030C30C3u;
+	v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+__global__ __launch_bounds__(256) void k_fine_keys(const float4 *__restrict__ rec, uint32_t n, float cx, float cy, float cz, float size,
+                                                    uint32_t *__restrict__ lo) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const float4 p = rec[i];
+	lo[i] = spread10(quant_lo10(p.x, cx, size)) | (spread10(quant_lo10(p.y, cy, size)) << 1) | (spread10(quant_lo10(p.z, cz, size)) << 2);
+}
+__global__ __launch_bounds__(256) void k_fine_keys_aos(const float *__restrict__ xyz, uint32_t n, float cx, float cy, float cz, float size,
+                                                        uint32_t *__restrict__ lo) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	lo[i] = spread10(quant_lo10(xyz[3ull * i + 0], cx, size)) | (spread10(quant_lo10(xyz[3ull * i + 1], cy, size)) << 1) |
+	        (spread10(quant_lo10(xyz[3ull * i + 2], cz, size)) << 2);
+}
+__global__ __launch_bounds__(256) void k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) dst[i] = src[idx[i]];
+}
+__global__ __launch_bounds__(256) void k_gather_rec(const float4 *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, float4 *__restrict__ dst,
+                                                     uint32_t *__restrict__ perm) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const float4 r = src[idx[i]];
+	dst[i] = r;
+	perm[i] = __float_as_uint(r.w);
+}
+
+// returns `sc` itself when no cell is long, else a re-sorted private copy
+int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &sc, std::shared_ptr<SortedCloud> *out) {
+	*out = sc;
+	const uint64_t n = sc->n;
+	static const bool off = getenv("TREEE_KNN_NO_REFINE") != nullptr; // A/B and test hook
+	if (n <= LONG_RUN || off) return TREEE_OK;
+	hipStream_t st = ctx->stream;
+	uint32_t flag = 0;
+	if (sc->crowded >= 0) { // the octree build already asked (its own host round trip carried the answer)
+		flag = (uint32_t)sc->crowded;
+	} else {
+		uint32_t *d_flag = nullptr;
+		TREEE_TRY(ctx->alloc_t(1, &d_flag));
+		TREEE_TRY(long_run_flag_dev(ctx, sc->d_keys, n, d_flag));
+		TREEE_HIP(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+		TREEE_HIP(hipStreamSynchronize(st));
+		sc->crowded = (int)flag;
+	}
+	if (!flag) return TREEE_OK;
+	auto fine = std::make_shared<SortedCloud>();
+	fine->n = n;
+	fine->device = sc->device;
+	fine->owner = ctx;
+	fine->size = sc->size;
+	for (int a = 0; a < 3; ++a) fine->corner[a] = sc->corner[a];
+	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_keys));
+	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_perm));
+	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_sorted));
+	uint32_t *d_lo = nullptr, *d_lo_s = nullptr, *d_pos1 = nullptr, *d_hi = nullptr, *d_pos2 = nullptr;
+	TREEE_TRY(ctx->alloc_t(n, &d_lo));
+	TREEE_TRY(ctx->alloc_t(n, &d_lo_s));
+	TREEE_TRY(ctx->alloc_t(n, &d_pos1));
+	TREEE_TRY(ctx->alloc_t(n, &d_hi));
+	TREEE_TRY(ctx->alloc_t(n, &d_pos2));
+	hipLaunchKernelGGL(k_fine_keys, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_sorted, (uint32_t)n, sc->corner[0], sc->corner[1], sc->corner[2],
+	                   sc->size, d_lo);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(sort_pairs_dev(ctx, d_lo, nullptr, n, 30, d_lo_s, d_pos1));
+	hipLaunchKernelGGL(k_gather_u32, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, d_pos1, (uint32_t)n, d_hi);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(sort_pairs_dev(ctx, d_hi, d_pos1, n, 30, fine->d_keys, d_pos2));
+	hipLaunchKernelGGL(k_gather_rec, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_sorted, d_pos2, (uint32_t)n, fine->d_sorted, fine->d_perm);
+	TREEE_LAUNCH_CHECK();
+	*out = fine;
+	return TREEE_OK;
+}
+
 // ---- segmented clouds: one logical KD-tree per segment (calculations.rs:97-118,329) in one structure ----------
 // segment id of every point in Morton order; ids outside [0, nseg) raise the error flag
 __global__ __launch_bounds__(256) void k_seg_gather(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ perm, uint32_t n, uint32_t nseg,
@@ -1228,6 +1322,26 @@ int32_t build_segmented(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_se
 	TREEE_HIP(hipMemsetAsync(d_bseg, 0xFF, nb_max * 4, st));
 	TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
 	TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, d_keys, d_perm));
+	{ // crowded Morton cells: order by the 20-bit-per-axis key instead (see refine_dense_cells)
+		uint32_t flag = 0;
+		static const bool off = getenv("TREEE_KNN_NO_REFINE") != nullptr;
+		if (n > LONG_RUN && !off) {
+			TREEE_TRY(long_run_flag_dev(ctx, d_keys, n, d_err));
+			TREEE_HIP(hipMemcpyAsync(&flag, d_err, 4, hipMemcpyDeviceToHost, st));
+			TREEE_HIP(hipStreamSynchronize(st));
+			TREEE_HIP(hipMemsetAsync(d_err, 0, 4, st));
+		}
+		if (flag) {
+			uint32_t *d_lo = d_sk, *d_lo_s = d_sks, *d_pos1 = d_perm2, *d_hi = d_keys; // buffers that are free at this point
+			hipLaunchKernelGGL(k_fine_keys_aos, dim3(div_up(n, 256)), dim3(256), 0, st, d_xyz, (uint32_t)n, sc->corner[0], sc->corner[1], sc->corner[2],
+			                   sc->size, d_lo);
+			TREEE_LAUNCH_CHECK();
+			TREEE_TRY(sort_pairs_dev(ctx, d_lo, nullptr, n, 30, d_lo_s, d_pos1));
+			hipLaunchKernelGGL(k_gather_u32, dim3(div_up(n, 256)), dim3(256), 0, st, d_keys_raw, d_pos1, (uint32_t)n, d_hi);
+			TREEE_LAUNCH_CHECK();
+			TREEE_TRY(sort_pairs_dev(ctx, d_hi, d_pos1, n, 30, d_lo, d_perm)); // d_lo: sorted keys, not needed again
+		}
+	}
 	hipLaunchKernelGGL(k_seg_gather, dim3(div_up(n, 256)), dim3(256), 0, st, d_seg, d_perm, (uint32_t)n, nseg, d_sk, d_err);
 	TREEE_LAUNCH_CHECK();
 	int bits = 1;
@@ -1312,7 +1426,8 @@ int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, tree
 		treee_knn_free(t);
 		return rc;
 	}
-	rc = build_bvh(ctx, t);
+	if (rc == TREEE_OK) rc = refine_dense_cells(ctx, t->sc, &t->sc);
+	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);
 		return rc;
@@ -1331,7 +1446,9 @@ int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_k
 	t->device = ctx->device;
 	t->sc = sc; // one Morton sort, two consumers
 	t->n_points = sc->n;
-	int32_t rc = build_bvh(ctx, t);
+	TREEE_TRY(ctx->reset());
+	int32_t rc = refine_dense_cells(ctx, sc, &t->sc); // (a private, finer-sorted copy if a Morton cell is crowded)
+	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);
 		return rc;

@@ -537,6 +537,18 @@ void SortedCloud::release() {
 	d_sorted = nullptr;
 }
 
+__global__ __launch_bounds__(256) void k_long_run(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ flag) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i + LONG_RUN < n && keys[i] == keys[i + LONG_RUN]) *flag = 1u; // benign race: every writer stores 1
+}
+
+int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t *d_flag) {
+	TREEE_HIP(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+	if (n > LONG_RUN) hipLaunchKernelGGL(k_long_run, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_keys, (uint32_t)n, d_flag);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc) {
 	sc->n = n;
 	sc->device = ctx->device;
