@@ -115,8 +115,9 @@ def main():
     def step(record):
         nonlocal halo
         if world > 1:
-            ghosts = stages.run("ghost_allgather", lambda: D.exchange_ghosts(pts, bounds, halo, rank, world, ctx=ctx), record)
-            cloud = torch.cat([pts, ghosts]) if ghosts.shape[0] else pts
+            if state.get("gx") is None:
+                state["gx"] = D.GhostExchanger(pts, bounds, halo, rank, world, ctx=ctx)
+            cloud = stages.run("ghost_allgather", lambda: state["gx"].exchange(halo), record)
         else:
             cloud = pts
         m = cloud.shape[0]

@@ -1,6 +1,8 @@
 """GPU parity tests proper: every call goes through the C ABI (libtreee_hip.so) and is compared
 with the CPU oracle on the same seeded inputs.  Bit-exact for integer / index / distance
 work; `curve` within 1e-5 (acos/cos: libm vs OCML)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -715,6 +717,53 @@ def test_shard_selection_matches_torch(T):
         m = (p[:, 0] >= x0 + 3.0) & (p[:, 0] < x1 - 4.0) & (p[:, 2] >= z0 - halo) & (p[:, 2] < z1 + halo)
         assert torch.equal(got, p[m])
     assert D.select_xz(pts[:0], (-inf, inf, -inf, inf), (0.0, 0.0, 0.0, 0.0)).shape[0] == 0
+
+
+def _gx_worker(rank, world, port, out_dir):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import treee_amd as T
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    dev = torch.device("cuda", 0)
+    plot, n = 20.0, 60_000
+    ctx = T.default_context(dev)
+    pts, _ = synth.forest_cloud_torch(n, dev, plot=plot, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, plot))
+    bounds = D.tile_bounds(rank, world, plot)
+    gx = D.GhostExchanger(pts, bounds, 0.5, rank, world, ctx=ctx, margin=1.05)
+    res = {}
+    for halo in (0.5, 0.5, 3.0):  # the last one outgrows the capacity sized for 0.5 m: every rank regrows together
+        cloud = gx.exchange(halo)
+        ref = D.exchange_ghosts(pts, bounds, halo, rank, world, ctx=ctx)
+        res[halo] = (torch.equal(cloud[:n], pts), cloud[n:].cpu(), ref.cpu())
+    torch.save(res, os.path.join(out_dir, f"gx{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_ghost_exchanger_matches_simple_exchange_two_ranks(T, tmp_path):
+    """the one-collective / one-round-trip exchanger against the straightforward exchange, 2 ranks sharing this GPU
+    (gloo, host-staged collectives)"""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_gx_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(tmp_path, f"gx{r}.pt"))
+        for halo, (own_ok, got, ref) in res.items():
+            assert own_ok
+            assert got.shape == ref.shape and got.shape[0] > 50, (halo, got.shape, ref.shape)
+            assert torch.equal(got, ref), halo  # same ghosts in the same order
 
 
 def test_onesweep_sort_variant_bit_exact(T):

@@ -152,6 +152,89 @@ def exchange_ghosts(points, bounds, halo, rank, world_size, group=None, ctx=None
     return torch.cat(keep) if keep else points[:0]
 
 
+class GhostExchanger:
+    """The per-step form of `exchange_ghosts` for clouds resident in HBM: ONE collective and ONE host round trip
+    per step instead of two and four.
+
+    * the cloud lives in a buffer with room for the ghosts behind the own points (`cloud[:n]` = own points,
+      `cloud[n:n+g]` = ghosts), so nothing is concatenated;
+    * the send block has a fixed capacity sized by one counted exchange at construction (times `margin`); its
+      row 0 is a header (x = the sender's count as int32 bits, y = z = NaN: never inside a box), unused rows are
+      NaN;
+    * receivers blank their own block and run ONE fused selection over all blocks straight into the ghost region;
+    * the host reads (ghost count, every sender's count) in one copy; a sender that outgrew the capacity is seen
+      by all ranks in the same data, so all of them grow the buffers together and repeat.
+    """
+
+    def __init__(self, points, bounds, halo, rank, world_size, ctx=None, group=None, margin=1.5):
+        from .context import default_context
+
+        assert points.is_cuda and world_size > 1
+        self.rank, self.world, self.group, self.bounds = rank, world_size, group, bounds
+        self.ctx = ctx or default_context(points.device)
+        self.n = points.shape[0]
+        self.dev = points.device
+        self.margin = margin
+        self.cnt = torch.zeros((2,), dtype=torch.int32, device=self.dev)
+        mine = self._select_boundary(points.contiguous(), halo, None, 0)  # counted once (synchronises)
+        count = torch.tensor([mine], dtype=torch.int64, device=self.dev)
+        most = int(_all_gather_equal(count, world_size, group).max().item())
+        self._allocate(points, int(most * margin) + 64)
+
+    def _allocate(self, points, cap):
+        self.cap = cap
+        self.ghost_cap = (self.world - 1) * cap
+        self.send = torch.empty((cap + 1, 3), dtype=torch.float32, device=self.dev)
+        self.recv = torch.empty((self.world, cap + 1, 3), dtype=torch.float32, device=self.dev)
+        self.cloud = torch.empty((self.n + self.ghost_cap, 3), dtype=torch.float32, device=self.dev)
+        self.cloud[: self.n] = points
+
+    def _select_boundary(self, points, halo, out, cap):
+        """own points within `halo` of a shared face -> out (or just counted when out is None)."""
+        import numpy as np
+
+        from . import _lib
+        from .context import ptr
+
+        faces = _interior_faces(self.rank, self.world)
+        x0, x1, z0, z1 = self.bounds
+        keep = np.asarray((-_INF, _INF, -_INF, _INF), dtype=np.float32)
+        drop = np.asarray((x0 + halo if faces[0] else -_INF, x1 - halo if faces[1] else _INF, z0 + halo if faces[2] else -_INF,
+                           z1 - halo if faces[3] else _INF), dtype=np.float32)
+        _lib.check(_lib.lib().treee_select_xz_dev(self.ctx.handle, ptr(points), points.shape[0], ptr(keep), ptr(drop), ptr(out), cap, ptr(self.cnt)))
+        return int(self.cnt[0].item()) if out is None else None
+
+    def exchange(self, halo):
+        """refreshes the ghosts behind the own points; returns cloud[: n + ghosts]."""
+        import numpy as np
+
+        from . import _lib
+        from .context import ptr
+
+        x0, x1, z0, z1 = self.bounds
+        while True:
+            cap = self.cap
+            self.send.fill_(float("nan"))
+            self._select_boundary(self.cloud[: self.n], halo, self.send[1:], cap)
+            self.send.view(torch.int32)[0, 0:1].copy_(self.cnt[0:1])
+            if _host_staged(self.group):
+                self.recv.copy_(_all_gather_equal(self.send, self.world, self.group))
+            else:
+                dist.all_gather_into_tensor(self.recv.view(-1, 3), self.send, group=self.group)
+            heads = self.recv.view(torch.int32)[:, 0, 0].clone()
+            self.recv[self.rank].fill_(float("nan"))
+            keep = np.asarray((x0 - halo, x1 + halo, z0 - halo, z1 + halo), dtype=np.float32)
+            drop = np.zeros(4, np.float32)
+            flat = self.recv.view(-1, 3)
+            _lib.check(_lib.lib().treee_select_xz_dev(self.ctx.handle, ptr(flat), flat.shape[0], ptr(keep), ptr(drop), ptr(self.cloud[self.n :]),
+                                                      self.ghost_cap, ptr(self.cnt[1:])))
+            info = torch.cat([self.cnt[1:2], heads]).tolist()  # the step's one host round trip
+            ghosts, most = info[0], max(info[1:])
+            if most <= cap and ghosts <= self.ghost_cap:
+                return self.cloud[: self.n + ghosts]
+            self._allocate(self.cloud[: self.n].clone(), int(max(most, cap) * self.margin) + 64)  # same decision on every rank
+
+
 def halo_is_sufficient(points, kth_dist_sq, bounds, halo, rank, world_size, group=None):
     """True on every rank iff every own query's k-th neighbour lies inside the region the halo
     covers: sqrt(d_k) <= distance to the nearest shared face + halo."""
