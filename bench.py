@@ -237,6 +237,7 @@ def main():
             out["hbm_copy_GBps"] = measured_copy_gbps(dev)
             out["ingest"] = ingest_stage(n, dev, ctx)
             out["per_segment_knn"] = segment_stage(pts, seg, ctx)
+            out["eye_dome"] = eye_dome_stage(depth, ctx)
             out["out_of_core"] = out_of_core_stage(dev, n, proj)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
@@ -303,6 +304,26 @@ def ingest_stage(n, dev, ctx):
         "slice_bin_frac": round(b_bin * n / (res["slice_bin"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "Mpoints_per_s": round(n / ((res["decode"] + res["slice_bin"]) * 1e-3) / 1e6, 1),
     }
+
+
+def eye_dome_stage(depth, ctx):
+    """the eye-dome pass (render/src/eye_dome.wgsl:37-67) over the step's depth frame, and over an
+    8K frame where the launch is long enough to read a bandwidth from (4 B read + 4 B written per pixel)."""
+    import treee_amd as T
+
+    res = {}
+    big = depth.repeat(4, 4).contiguous()  # 7680 x 4320
+    for name, d in (("1080p", depth), ("8k", big)):
+        T.eye_dome_dev(d, 0.7, ctx)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            T.eye_dome_dev(d, 0.7, ctx)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        res[name] = {"ms": round(ms, 4), "achieved_GBps": round(8 * d.numel() / (ms * 1e-3) / 1e9, 1), "frac": round(8 * d.numel() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return res
 
 
 def segment_stage(pts, seg, ctx):

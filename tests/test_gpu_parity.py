@@ -336,6 +336,25 @@ def test_splat_value_cull_ties_and_device_path(T, oracle):
         T.PointCloud(pts).render(T.PointCloudProperty(val), view, bad, env, w, h)
 
 
+@pytest.mark.parametrize("w,h", [(320, 180), (322, 181), (4, 1), (8, 3)])
+def test_eye_dome_bit_exact(T, oracle, w, h):
+    """render/src/eye_dome.wgsl over a real depth frame: vectorised path (w % 4 == 0) and scalar path"""
+    import torch
+
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(60_000, plot=30.0)
+    cam = T.Camera3D(w / h)
+    view = T.view_from_transform(T.rotation_x(-0.4) @ T.translation(0.0, 0.0, 60.0))
+    depth, _ = T.PointCloud(torch.from_numpy(pts).cuda()).render(
+        T.PointCloudProperty(torch.from_numpy(seg.astype(np.int32)).cuda()), view, cam.projection(), T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.4), w, h)
+    for strength in (0.0, 0.7, 0.95):
+        got = T.eye_dome_dev(depth, strength).cpu().numpy()
+        ref = oracle.eye_dome(depth.cpu().numpy(), max(1 - strength, 0.1) ** 6)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert (depth < 1).any() or w * h < 64
+
+
 # ---------------------------------------------------------------- A8-A9 ingest
 @pytest.mark.parametrize("stride,fmt", [(20, 0), (28, 1), (26, 2), (34, 3)])
 def test_las_decode_bit_exact(T, oracle, stride, fmt):

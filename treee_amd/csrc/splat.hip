@@ -129,6 +129,45 @@ __device__ __forceinline__ float ed_depth(const float *__restrict__ depth, int w
 	return (2.0f * near) / (far + near - d * (far - near));
 }
 
+__device__ __forceinline__ float ed_lin(float d) { // linearised depth of one texel (eye_dome.wgsl:37-45)
+	const float near = 0.1f, far = 10000.0f;
+	if (d >= 1.0f) return 1.0f;
+	return (2.0f * near) / (far + near - d * (far - near));
+}
+
+// one thread = 4 horizontally adjacent pixels: three 16-byte row loads (above, centre, below) + the two scalars
+// left and right of the quad; 64 x 4 threads = a 256 x 4 pixel tile per workgroup.  Same arithmetic as the scalar
+// form (ed_depth), which handles widths that are not a multiple of 4.
+__global__ __launch_bounds__(256) void k_eye_dome4(const float *__restrict__ depth, uint32_t w, uint32_t h, float strength, float *__restrict__ alpha) {
+	const uint32_t x0 = (blockIdx.x * 64u + (threadIdx.x & 63u)) * 4u, y = blockIdx.y * 4u + (threadIdx.x >> 6);
+	if (x0 >= w || y >= h) return;
+	const uint32_t yu = y == 0 ? 0 : y - 1, yd = y + 1 >= h ? h - 1 : y + 1;
+	const float4 c = *(const float4 *)(depth + (size_t)y * w + x0);
+	const float4 u = *(const float4 *)(depth + (size_t)yu * w + x0);
+	const float4 dn = *(const float4 *)(depth + (size_t)yd * w + x0);
+	const float lf = depth[(size_t)y * w + (x0 == 0 ? 0 : x0 - 1)], rt = depth[(size_t)y * w + (x0 + 4 >= w ? w - 1 : x0 + 4)];
+	const float cc[6] = {ed_lin(lf), ed_lin(c.x), ed_lin(c.y), ed_lin(c.z), ed_lin(c.w), ed_lin(rt)};
+	const float uu[4] = {ed_lin(u.x), ed_lin(u.y), ed_lin(u.z), ed_lin(u.w)};
+	const float dd[4] = {ed_lin(dn.x), ed_lin(dn.y), ed_lin(dn.z), ed_lin(dn.w)};
+	float out[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const float d = cc[j + 1];
+		float a = 0.0f;
+		if (d != 1.0f) {
+			float m = d;
+			m = fmaxf(m, cc[j]);
+			m = fmaxf(m, cc[j + 2]);
+			m = fmaxf(m, uu[j]);
+			m = fmaxf(m, dd[j]);
+			m = fminf(m, d + strength);
+			a = (m - d) / strength;
+		}
+		out[j] = a;
+	}
+	*(float4 *)(alpha + (size_t)y * w + x0) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 __global__ __launch_bounds__(256) void k_eye_dome(const float *__restrict__ depth, uint32_t w, uint32_t h, float strength, float *__restrict__ alpha) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= w * h) return;
@@ -253,7 +292,10 @@ int32_t treee_perspective(float aspect, float fovy, float znear, float zfar, flo
 int32_t treee_eye_dome_dev(treee_ctx *ctx, const float *d_depth, uint32_t w, uint32_t h, float strength, float *d_alpha) {
 	if (!ctx || !d_depth || !d_alpha) return set_err(TREEE_ERR_INVALID, "treee_eye_dome_dev: null argument");
 	TREEE_HIP(hipSetDevice(ctx->device));
-	hipLaunchKernelGGL(k_eye_dome, dim3(div_up((uint64_t)w * h, 256)), dim3(256), 0, ctx->stream, d_depth, w, h, strength, d_alpha);
+	if (w % 4 == 0 && ((uintptr_t)d_depth % 16) == 0 && ((uintptr_t)d_alpha % 16) == 0)
+		hipLaunchKernelGGL(k_eye_dome4, dim3(div_up(w, 256), div_up(h, 4)), dim3(256), 0, ctx->stream, d_depth, w, h, strength, d_alpha);
+	else
+		hipLaunchKernelGGL(k_eye_dome, dim3(div_up((uint64_t)w * h, 256)), dim3(256), 0, ctx->stream, d_depth, w, h, strength, d_alpha);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
 }
