@@ -41,34 +41,38 @@ namespace {
 constexpr int BUCKET = 64;
 
 // ---- bucket AABBs and the implicit tree ---------------------------------------------------------
+// 16 lanes per bucket, 4 consecutive records per lane (64 contiguous bytes): a wave covers 4 buckets = 4 KiB, the
+// per-lane fold needs no cross-lane traffic and the butterfly has 4 steps instead of 6.
 __global__ __launch_bounds__(256) void k_leaf_aabb(const float4 *__restrict__ pts, uint32_t n, uint32_t nb, uint32_t P,
                                                     const uint32_t *__restrict__ bucket_seg /* or null */, float4 *__restrict__ bvh) {
-	const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
-	if (b >= P) return;
-	const int lane = threadIdx.x & 63;
-	const uint32_t i = b * BUCKET + lane;
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	const uint32_t b = t >> 4; // bucket
+	if (b >= P) return;        // whole groups of 16 lanes leave together (the shuffles below stay inside a group)
+	const uint32_t i0 = b * BUCKET + (t & 15u) * 4u;
 	float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-	if (b < nb && i < n) {
-		const float4 p = pts[i];
-		mn[0] = mx[0] = p.x;
-		mn[1] = mx[1] = p.y;
-		mn[2] = mx[2] = p.z;
-		// NaN coordinates never produce a valid distance; keep them out of the boxes
+	if (b < nb) {
 #pragma unroll
-		for (int a = 0; a < 3; ++a)
-			if (mn[a] != mn[a]) {
-				mn[a] = INFINITY;
-				mx[a] = -INFINITY;
+		for (int j = 0; j < 4; ++j) {
+			if (i0 + j < n) {
+				const float4 p = pts[i0 + j];
+				const float c[3] = {p.x, p.y, p.z};
+				// NaN coordinates never produce a valid distance; keep them out of the boxes (fminf/fmaxf drop a NaN operand)
+#pragma unroll
+				for (int a = 0; a < 3; ++a) {
+					mn[a] = fminf(mn[a], c[a]);
+					mx[a] = fmaxf(mx[a], c[a]);
+				}
 			}
+		}
 	}
 #pragma unroll
 	for (int a = 0; a < 3; ++a)
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
+		for (int o = 8; o > 0; o >>= 1) {
 			mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
 			mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
 		}
-	if (lane == 0) {
+	if ((t & 15u) == 0) {
 		// .w = segment range of the node (uint bits): [s, s] for a bucket of segment s, the empty range [~0, 0]
 		// for an unused leaf, [0, 0] everywhere when the cloud is not segmented
 		uint32_t slo = 0u, shi = 0u;
@@ -90,6 +94,22 @@ __global__ __launch_bounds__(256) void k_inner_aabb(float4 *__restrict__ bvh, ui
 	const uint32_t slo = min(__float_as_uint(a0.w), __float_as_uint(b0.w)), shi = max(__float_as_uint(a1.w), __float_as_uint(b1.w));
 	bvh[2ull * i + 0] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), __uint_as_float(slo));
 	bvh[2ull * i + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), __uint_as_float(shi));
+}
+
+// the top of the tree (levels of at most INNER_TOP nodes) in one workgroup: a level per barrier instead of a launch
+constexpr uint32_t INNER_TOP = 1024;
+__global__ __launch_bounds__(INNER_TOP) void k_inner_aabb_top(float4 *__restrict__ bvh, uint32_t first_level) {
+	for (uint32_t lvl = first_level; lvl >= 1; lvl >>= 1) {
+		if (threadIdx.x < lvl) {
+			const uint32_t i = lvl + threadIdx.x;
+			const float4 a0 = bvh[4ull * i + 0], a1 = bvh[4ull * i + 1], b0 = bvh[4ull * i + 2], b1 = bvh[4ull * i + 3];
+			const uint32_t slo = min(__float_as_uint(a0.w), __float_as_uint(b0.w)), shi = max(__float_as_uint(a1.w), __float_as_uint(b1.w));
+			bvh[2ull * i + 0] = make_float4(fminf(a0.x, b0.x), fminf(a0.y, b0.y), fminf(a0.z, b0.z), __uint_as_float(slo));
+			bvh[2ull * i + 1] = make_float4(fmaxf(a1.x, b1.x), fmaxf(a1.y, b1.y), fmaxf(a1.z, b1.z), __uint_as_float(shi));
+		}
+		__threadfence_block();
+		__syncthreads(); // the next level reads what this one wrote (same workgroup: write-through L1, never read before)
+	}
 }
 
 // ---- per-lane top-k: binary max-heap in LDS, total order (distance bits, sorted position) ------
@@ -1267,9 +1287,11 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t, const uint32_t *d_bucket_seg = n
 	while (t->P < t->nb) t->P <<= 1;
 	t->owner = ctx;
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->P * 2 * 2, &t->d_bvh));
-	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 4)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, d_bucket_seg, t->d_bvh);
-	for (uint32_t lvl = t->P >> 1; lvl >= 1; lvl >>= 1) // nodes [lvl, 2*lvl)
+	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 16)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, d_bucket_seg, t->d_bvh);
+	uint32_t lvl = t->P >> 1;
+	for (; lvl > INNER_TOP; lvl >>= 1) // nodes [lvl, 2*lvl)
 		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
+	if (lvl >= 1) hipLaunchKernelGGL(k_inner_aabb_top, dim3(1), dim3(INNER_TOP), 0, ctx->stream, t->d_bvh, lvl); // the levels that fit one workgroup
 	TREEE_LAUNCH_CHECK();
 	// dispatch table of the self-query kernel: a stable radix sort of the buckets by (XCD label, size class),
 	// then the 8 label segments interleaved
