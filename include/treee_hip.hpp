@@ -1,0 +1,203 @@
+// treee_hip.hpp -- C++ host-side mirror of the reference's Rust interfaces for the hot path, above the C ABI
+// (treee_hip.h).  Header-only; link with -ltreee_hip.
+//
+// The reference is compiled Rust and no Rust toolchain exists in the build image, so the host side that a Rust
+// maintainer would write as `impl` blocks is provided here in C++ with the same names, argument
+// meaning and error behaviour:
+//
+//   k_nearest::KDTree<3, f32, ..>::{new, k_nearest, nearest_to_position, nearest, empty}   k-nearest/src/kd_tree.rs:35-102
+//   k_nearest::Entry<f32>                                                                   k-nearest/src/kd_tree.rs:8-12
+//   NeighborsTree::{new, get}                                                               treee/src/calculations.rs:392-419
+//   the `curve` branch of SegmentInformation::update, map_to_u32                             treee/src/calculations.rs:328-373,455-457
+//   render::PointCloud::render into a depth + id buffer, PointCloudEnvironment              render/src/point_cloud.rs:148-173,206-243
+//   Camera3D projection                                                                     render/src/camera_3d.rs:16-18
+//   laz::Chunk::read, the slice key of the load worker                                      treee/src/laz.rs:193-213, loading.rs:99
+//
+// Where the reference panics (KDTree::new on an empty slice, k == 0, mismatched property length) these wrappers
+// throw treee::Error; nothing else changes.  There is no CPU fallback underneath: without a HIP device every call
+// throws.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "treee_hip.h"
+
+namespace treee {
+
+using Point3 = std::array<float, 3>; // nalgebra::Point3<f32>: 3 contiguous f32 (render/src/point.rs:25-31)
+static_assert(sizeof(Point3) == 12, "Point3 must be 12 bytes, AoS");
+
+struct Error : std::runtime_error {
+	int32_t code;
+	Error(int32_t c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+inline void check(int32_t rc) {
+	if (rc != TREEE_OK) throw Error(rc, treee_last_error());
+}
+
+// k_nearest::Entry<f32> (kd_tree.rs:8-12); index == SIZE_MAX marks an unused slot ("initial values are never read")
+struct Entry {
+	float distance; // SQUARED euclidean distance
+	size_t index;
+};
+
+// k_nearest::KDTree<3, f32, Point3<f32>, Adapter, EuclideanDistanceSquared>
+class KDTree {
+public:
+	// KDTree::new(&[Point]) (kd_tree.rs:35-42): copies the coordinates; panics (here: throws) on an empty slice
+	explicit KDTree(const std::vector<Point3> &points) : KDTree(points.empty() ? nullptr : points[0].data(), points.size()) {}
+	KDTree(const float *xyz_aos, size_t n) { check(treee_knn_build(xyz_aos, n, &h_)); }
+	KDTree(const KDTree &) = delete;
+	KDTree &operator=(const KDTree &) = delete;
+	KDTree(KDTree &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+	~KDTree() { treee_knn_free(h_); }
+
+	// KDTree::k_nearest(&Point, &mut [Entry], max_distance) -> usize (kd_tree.rs:82-84): fills `location` (its
+	// length is k), returns the number of valid entries; ascending; every distance < max_distance (strict)
+	size_t k_nearest(const Point3 &point, std::vector<Entry> &location, float max_distance) const {
+		return nearest_to_position(point.data(), location.data(), location.size(), max_distance);
+	}
+	// KDTree::nearest_to_position(&[f32; 3], ..) (kd_tree.rs:92-96)
+	size_t nearest_to_position(const float position[3], Entry *location, size_t k, float max_distance) const {
+		std::vector<treee_entry> raw(k);
+		uint32_t count = 0;
+		check(treee_knn_query_batch(h_, position, 1, (uint32_t)k, max_distance, raw.data(), &count));
+		for (size_t i = 0; i < k; ++i) location[i] = Entry{raw[i].distance, raw[i].index == UINT64_MAX ? SIZE_MAX : (size_t)raw[i].index};
+		return count;
+	}
+	// the same for many positions at once (one launch): out[nq * k], counts[nq]
+	void k_nearest_batch(const float *positions, size_t nq, size_t k, float max_distance, std::vector<Entry> &out, std::vector<uint32_t> &counts) const {
+		std::vector<treee_entry> raw(nq * k);
+		counts.assign(nq, 0);
+		check(treee_knn_query_batch(h_, positions, nq, (uint32_t)k, max_distance, raw.data(), counts.data()));
+		out.resize(nq * k);
+		for (size_t i = 0; i < nq * k; ++i) out[i] = Entry{raw[i].distance, raw[i].index == UINT64_MAX ? SIZE_MAX : (size_t)raw[i].index};
+	}
+	// KDTree::nearest(&Point, max_distance) -> Vec<Entry> (kd_tree.rs:86-90): all points with d < max, ascending
+	std::vector<Entry> nearest(const Point3 &point, float max_distance) const {
+		uint64_t found = 0;
+		check(treee_knn_radius(h_, point.data(), max_distance, nullptr, 0, &found));
+		std::vector<treee_entry> raw(found);
+		if (found) check(treee_knn_radius(h_, point.data(), max_distance, raw.data(), found, &found));
+		std::vector<Entry> out(raw.size());
+		for (size_t i = 0; i < raw.size(); ++i) out[i] = Entry{raw[i].distance, (size_t)raw[i].index};
+		return out;
+	}
+	// KDTree::empty(&Point, max_distance) -> bool (kd_tree.rs:98-102)
+	bool empty(const Point3 &point, float max_distance) const {
+		uint8_t e = 0;
+		check(treee_knn_empty(h_, point.data(), 1, max_distance, &e));
+		return e != 0;
+	}
+	size_t len() const {
+		uint64_t n = 0;
+		check(treee_knn_len(h_, &n));
+		return (size_t)n;
+	}
+	const treee_knn *handle() const { return h_; }
+
+private:
+	treee_knn *h_ = nullptr;
+};
+
+// treee/src/calculations.rs:392-419
+class NeighborsTree {
+public:
+	explicit NeighborsTree(const std::vector<Point3> &points) : tree_(points) {}
+	// NeighborsTree::get(index, data, location, max_distance) -> &location[0..l]
+	std::pair<const Entry *, size_t> get(size_t index, const std::vector<Point3> &data, std::vector<Entry> &location, float max_distance) const {
+		const size_t l = tree_.k_nearest(data[index], location, max_distance);
+		return {location.data(), l};
+	}
+
+private:
+	KDTree tree_;
+};
+
+constexpr uint32_t NEIGHBORS_COUNT = 31;                                 // calculations.rs:278
+constexpr float NEIGHBORS_MAX_DISTANCE = std::numeric_limits<float>::max(); // calculations.rs:279
+
+// the `curve` vector of SegmentInformation::update(calc_curve = true) (calculations.rs:328-373) for one segment
+inline std::vector<float> curvature(const std::vector<Point3> &data, uint32_t neighbors_count = NEIGHBORS_COUNT,
+                                    float neighbors_max_distance = NEIGHBORS_MAX_DISTANCE) {
+	std::vector<float> curve(data.size());
+	if (!data.empty()) check(treee_curvature(data[0].data(), data.size(), neighbors_count, neighbors_max_distance, curve.data()));
+	return curve;
+}
+// ... and for every segment of a segmented cloud in one pass (`segment` = the Vec<u32> kept beside the points)
+inline std::vector<float> curvature_segments(const std::vector<Point3> &data, const std::vector<uint32_t> &segment, uint32_t n_segments,
+                                             uint32_t neighbors_count = NEIGHBORS_COUNT, float neighbors_max_distance = NEIGHBORS_MAX_DISTANCE) {
+	if (segment.size() != data.size()) throw Error(TREEE_ERR_INVALID, "segment.len() != points.len()");
+	std::vector<float> curve(data.size());
+	if (!data.empty())
+		check(treee_curvature_segments(data[0].data(), segment.data(), data.size(), n_segments, neighbors_count, neighbors_max_distance, curve.data()));
+	return curve;
+}
+// map_to_u32 (calculations.rs:455-457): (value * u32::MAX as f32) as u32, saturating like Rust's `as`
+inline uint32_t map_to_u32(float value) {
+	const float v = value * 4294967296.0f; // u32::MAX as f32 rounds to 2^32
+	if (!(v > 0.0f)) return 0u;            // negative or NaN
+	if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+	return (uint32_t)v;
+}
+
+// render: Camera3D projection (camera_3d.rs:16-18), PointCloudEnvironment (point_cloud.rs:206-243), the draw
+struct PointCloudEnvironment {
+	uint32_t min = 0, max = 0xFFFFFFFFu;
+	float scale = 0.1f; // program.rs:156
+};
+inline std::array<float, 16> perspective(float aspect, float fovy, float znear, float zfar) { // column-major like nalgebra
+	std::array<float, 16> m{};
+	check(treee_perspective(aspect, fovy, znear, zfar, m.data()));
+	return m;
+}
+struct Frame {
+	uint32_t width = 0, height = 0;
+	std::vector<float> depth; // Depth32Float, cleared to 1.0 (window.rs:153-159)
+	std::vector<uint32_t> id; // property value of the nearest point per pixel, 0 where nothing was drawn
+};
+// PointCloud::render(property, environment) with a depth + id target (point_cloud.rs:148-173 + point_cloud.wgsl)
+inline Frame render(const std::vector<Point3> &vertices, const std::vector<uint32_t> &property, const float view[16], const float proj[16],
+                    const PointCloudEnvironment &env, uint32_t width, uint32_t height) {
+	if (property.size() != vertices.size()) throw Error(TREEE_ERR_INVALID, "property.len() != vertices.len() (point_cloud.rs:161-167)");
+	Frame f;
+	f.width = width;
+	f.height = height;
+	f.depth.assign((size_t)width * height, 1.0f);
+	f.id.assign((size_t)width * height, 0u);
+	check(treee_splat(vertices.empty() ? nullptr : vertices[0].data(), property.data(), vertices.size(), view, proj, env.scale, env.min, env.max,
+	                  width, height, f.depth.data(), f.id.data()));
+	return f;
+}
+
+namespace laz {
+// laz.rs:184-213: raw record bytes + the decode parameters
+struct Chunk {
+	const uint8_t *slice = nullptr;
+	size_t slice_len = 0, point_length = 0;
+	double offset[3] = {0, 0, 0}, scale[3] = {1, 1, 1}, center[3] = {0, 0, 0};
+	// Chunk::read(self) -> Vec<Point3<f32>> (laz.rs:193-200)
+	std::vector<Point3> read() const {
+		const size_t n = point_length ? slice_len / point_length : 0;
+		std::vector<Point3> res(n);
+		if (n) check(treee_decode_las_records(slice, n, (uint32_t)point_length, scale, offset, center, res[0].data()));
+		return res;
+	}
+};
+} // namespace laz
+
+// loading.rs:99: idx = p.y.floor() as isize, for a whole chunk
+inline std::vector<int64_t> slice_keys(const std::vector<Point3> &points) {
+	std::vector<int64_t> keys(points.size());
+	if (!points.empty()) check(treee_slice_keys(points[0].data(), points.size(), keys.data()));
+	return keys;
+}
+
+} // namespace treee

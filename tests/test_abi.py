@@ -103,3 +103,16 @@ def test_product_package_never_imports_the_oracle():
                 assert "oracle" not in text.replace("oracle/", "oracle_dir/").replace("the oracle", "").replace("against oracle_dir", "") or \
                     re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle", text, re.M) is None, f
                 assert re.search(r"^\s*(from|import)\s+oracle|#include\s+\"[^\"]*oracle|dlopen|libtreee_oracle", text, re.M) is None, f
+
+
+def test_cpp_host_mirror_compiles_and_links():
+    """the header-only C++ mirror builds with plain g++ against the shared library (no GPU needed to link)"""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as G
+
+    G.build()
+    exe = G.build_host_mirror_test()
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)

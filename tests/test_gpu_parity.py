@@ -785,6 +785,22 @@ def test_ghost_exchanger_matches_simple_exchange_two_ranks(T, tmp_path):
             assert torch.equal(got, ref), halo  # same ghosts in the same order
 
 
+def test_cpp_host_mirror_program(T):
+    """include/treee_hip.hpp (the C++ mirror of KDTree / NeighborsTree / render / laz::Chunk above the C ABI) in a
+    plain C++ process without torch: the program compares every call with the oracle and exits 0"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as G
+
+    exe = G.build_host_mirror_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
+
+
 def test_onesweep_sort_variant_bit_exact(T):
     """the optional onesweep radix passes (decoupled look-back across workgroups, TREEE_SORT_ONESWEEP=1)
     must give the same bits as the default hist/scan/scatter passes"""
