@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--halo", type=float, default=2.0)
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="points of the CPU-baseline sample (about 10-30 s of oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (ingest, per-segment kNN, eye-dome, out-of-core stream): profiling runs")
     return ap.parse_args()
 
 
@@ -233,7 +234,7 @@ def main():
             "stages": stage_roof,
             "end_to_end_GBps": round((sum(BYTES.values()) * n + 24 * W * H) / (elapsed / args.steps) / 1e9 * world, 1),
         }
-        if world == 1 and n == 15_000_000:
+        if world == 1 and n == 15_000_000 and not args.no_extras:
             out["hbm_copy_GBps"] = measured_copy_gbps(dev)
             out["ingest"] = ingest_stage(n, dev, ctx)
             out["per_segment_knn"] = segment_stage(pts, seg, ctx)

@@ -8,9 +8,9 @@ repo=$PWD
 out=$repo/gpurun_out/$tag
 rm -rf $out && mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $out/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/write.log 2>&1
 cd $repo
 python profiles/summarize.py $out $tag
 python bench.py > $out/bench_default.json 2> $out/bench_default.err
