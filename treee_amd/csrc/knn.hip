@@ -430,6 +430,43 @@ template <int N> __device__ __forceinline__ void bitonic_sort(double (&v)[N]) {
 	}
 }
 
+// Sorting networks with fewer comparators than the bitonic sorter (the kernel is VALU-issue bound and a
+// compare-exchange is 2 VALU).  16 inputs: the 60-comparator, 10-layer network (bitonic: 80); verified with the 0-1
+// principle over all 2^16 inputs.  32 inputs: Batcher's odd-even merge sort, 191 comparators (bitonic: 240).
+__device__ __forceinline__ void sort16_net(double (&v)[16]) {
+#define CX(a, b) cmpx(v[a], v[b])
+	CX(0, 13); CX(1, 12); CX(2, 15); CX(3, 14); CX(4, 8); CX(5, 6); CX(7, 11); CX(9, 10);
+	CX(0, 5); CX(1, 7); CX(2, 9); CX(3, 4); CX(6, 13); CX(8, 14); CX(10, 15); CX(11, 12);
+	CX(0, 1); CX(2, 3); CX(4, 5); CX(6, 8); CX(7, 9); CX(10, 11); CX(12, 13); CX(14, 15);
+	CX(0, 2); CX(1, 3); CX(4, 10); CX(5, 11); CX(6, 7); CX(8, 9); CX(12, 14); CX(13, 15);
+	CX(1, 2); CX(3, 12); CX(4, 6); CX(5, 7); CX(8, 10); CX(9, 11); CX(13, 14);
+	CX(1, 4); CX(2, 6); CX(5, 8); CX(7, 10); CX(9, 13); CX(11, 14);
+	CX(2, 4); CX(3, 6); CX(9, 12); CX(11, 13);
+	CX(3, 5); CX(6, 8); CX(7, 9); CX(10, 12);
+	CX(3, 4); CX(5, 6); CX(7, 8); CX(9, 10); CX(11, 12);
+	CX(6, 7); CX(8, 9);
+#undef CX
+}
+template <int N> __device__ __forceinline__ void odd_even_merge_sort(double (&v)[N]) {
+#pragma unroll
+	for (int p = 1; p < N; p <<= 1)
+#pragma unroll
+		for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+			for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+#pragma unroll
+				for (int i = 0; i < k; ++i)
+					if (i + j + k < N && (i + j) / (2 * p) == (i + j + k) / (2 * p)) cmpx(v[i + j], v[i + j + k]);
+}
+template <int N> __device__ __forceinline__ void sort_net(double (&v)[N]) {
+	if constexpr (N == 16)
+		sort16_net(v);
+	else if constexpr (N == 32)
+		odd_even_merge_sort<32>(v);
+	else
+		bitonic_sort<N>(v);
+}
+
 template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) { // v bitonic -> ascending
 #pragma unroll
 	for (int j = N >> 1; j > 0; j >>= 1) {
@@ -538,7 +575,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 			const uint32_t pos = buf[s * 64 + lane], db = buf[SBUF * 64 + s * 64 + lane];
 			B[s] = wofs0 + (uint32_t)s * 256u < wofs ? key_make(db, pos) : __longlong_as_double((long long)KEY_MAX);
 		}
-		bitonic_sort<SBUF>(B);
+		sort_net<SBUF>(B);
 #pragma unroll
 		for (int i = SK - SBUF; i < SK; ++i) L[i] = key_min(L[i], B[SK - 1 - i]); // 32 smallest of the union, bitonic
 		bitonic_merge<SK>(L);
@@ -634,7 +671,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 				L[j] = d0 < a.maxbits ? key_make(d0, base + j) : key_make(a.maxbits, 0u); // strict `<` (best_set.rs:20-28)
 				L[j + 1] = d1 < a.maxbits ? key_make(d1, base + j + 1) : key_make(a.maxbits, 0u);
 			}
-			bitonic_sort<SK>(L);
+			sort_net<SK>(L);
 			thr = key_db(L[SK - 1]);
 			ST(if (a.thr_io && a.thr_seed && live) thr = min(thr, a.thr_io[slot]));
 			first = SK;
