@@ -126,6 +126,17 @@ def main():
         # ONE Morton sort per step: the octree is built over the shard plus its boundary ghosts and the
         # kNN structure shares that sorted cloud by reference
         oc = stages.run("keys_sort_octree", lambda: T.Octree(cloud, ctx=ctx), record)
+        pending = None
+        if world > 1:
+            # The environment culls nothing (min 0, max u32::MAX), so the packed (depth, index) frame depends on
+            # positions only: draw it now and let RCCL min-reduce it on its own stream UNDER the kNN kernel; the
+            # values are looked up by the resolve pass once the curvature exists.
+            def draw():
+                T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj),
+                                                     env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, rank * n, None, None))
+                return D.reduce_packed_min_async(packed)
+
+            pending = stages.run("splat", draw, record)
         tree = stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
         cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
         stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv), record)
@@ -133,13 +144,18 @@ def main():
 
         def splat():
             T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), T.context.ptr(val), n, T.context.ptr(view), T.context.ptr(proj),
-                                                 env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, rank * n, None, None))
-            if world > 1:
-                D.reduce_packed_min(packed)
+                                                 env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, 0, None, None))
             T._lib.check(T.lib().treee_splat_resolve_dev(ctx.handle, T.context.ptr(packed), T.context.ptr(val), n, W, H, T.context.ptr(depth),
-                                                         T.context.ptr(ids) if world == 1 else None))
+                                                         T.context.ptr(ids)))
 
-        stages.run("splat", splat, record)
+        def resolve():
+            pending.wait()
+            T._lib.check(T.lib().treee_splat_resolve_dev(ctx.handle, T.context.ptr(packed), T.context.ptr(val), n, W, H, T.context.ptr(depth), None))
+
+        if world > 1:
+            stages.run("frame_reduce_wait_resolve", resolve, record)
+        else:
+            stages.run("splat", splat, record)
         state["oc"], state["tree"], state["curve"], state["cloud_n"] = oc, tree, cv, m
         return oc, tree
 

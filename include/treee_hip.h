@@ -168,7 +168,10 @@ int32_t treee_octree_dev_ptr(const treee_octree *o, int32_t what, void **d_ptr_o
 int32_t treee_splat(const float *xyz_aos, const uint32_t *value, uint64_t n, const float view[16],
                     const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w,
                     uint32_t h, float *depth_out, uint32_t *id_out);
-/* d_packed (optional, u64[w*h]) receives (depth_bits << 32 | point index) for cross-GPU
+/* d_value may be NULL when the environment culls nothing (vmin = 0, vmax = UINT32_MAX) and no id buffer is
+ * requested: the packed frame then depends on positions only and can be drawn -- and, across GPUs, reduced --
+ * before the values exist (treee_splat_resolve_dev looks them up afterwards).
+ * d_packed (optional, u64[w*h]) receives (depth_bits << 32 | point index) for cross-GPU
  * min-reduction; when accumulate != 0 the packed buffer is NOT cleared first and
  * index_base is added to the point index (multi-chunk / multi-GPU draws). */
 int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz_aos, const uint32_t *d_value, uint64_t n,

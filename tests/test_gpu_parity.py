@@ -336,6 +336,26 @@ def test_splat_value_cull_ties_and_device_path(T, oracle):
         T.PointCloud(pts).render(T.PointCloudProperty(val), view, bad, env, w, h)
 
 
+def test_splat_without_values_when_nothing_is_culled(T):
+    """the packed (depth, index) frame depends on positions only when the environment culls nothing: drawing with
+    d_value = NULL gives the same frame; with a culling range it is refused"""
+    import torch
+
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud_torch(80_000, "cuda", plot=25.0)
+    w, h = 320, 180
+    view, proj = default_camera(T, w, h)
+    ctx = T.default_context(torch.device("cuda", 0))
+    a = torch.empty((h, w), dtype=torch.int64, device="cuda")
+    b = torch.empty_like(a)
+    ptr = T.context.ptr
+    T._lib.check(T.lib().treee_splat_dev(ctx.handle, ptr(pts), ptr(seg), pts.shape[0], ptr(view), ptr(proj), 0.2, 0, 0xFFFFFFFF, w, h, ptr(a), 0, 7, None, None))
+    T._lib.check(T.lib().treee_splat_dev(ctx.handle, ptr(pts), None, pts.shape[0], ptr(view), ptr(proj), 0.2, 0, 0xFFFFFFFF, w, h, ptr(b), 0, 7, None, None))
+    assert torch.equal(a, b) and int((a != a.max()).sum()) > 1000
+    assert T.lib().treee_splat_dev(ctx.handle, ptr(pts), None, pts.shape[0], ptr(view), ptr(proj), 0.2, 1, 0xFFFFFFFF, w, h, ptr(b), 0, 0, None, None) == 1
+
+
 @pytest.mark.parametrize("w,h", [(320, 180), (322, 181), (4, 1), (8, 3)])
 def test_eye_dome_bit_exact(T, oracle, w, h):
     """render/src/eye_dome.wgsl over a real depth frame: vectorised path (w % 4 == 0) and scalar path"""

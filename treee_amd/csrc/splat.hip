@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_splat_points(const float *__restrict__ 
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	Foot f;
-	if (!footprint(P, xyz[3ull * i + 0], xyz[3ull * i + 1], xyz[3ull * i + 2], value[i], f)) return;
+	if (!footprint(P, xyz[3ull * i + 0], xyz[3ull * i + 1], xyz[3ull * i + 2], value ? value[i] : P.vmin, f)) return;
 	if ((f.x1 - f.x0) * (f.y1 - f.y0) > LARGE_AREA) {
 		large_list[atomicAdd(large_count, 1u)] = i;
 		return;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_splat_large(const float *__restrict__ x
 	for (uint32_t s = blockIdx.x; s < total; s += gridDim.x) {
 		const uint32_t i = large_list[s];
 		Foot f;
-		if (!footprint(P, xyz[3ull * i + 0], xyz[3ull * i + 1], xyz[3ull * i + 2], value[i], f)) continue;
+		if (!footprint(P, xyz[3ull * i + 0], xyz[3ull * i + 1], xyz[3ull * i + 2], value ? value[i] : P.vmin, f)) continue;
 		const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + i);
 		const int bw = f.x1 - f.x0;
 		const int area = bw * (f.y1 - f.y0);
@@ -201,7 +201,9 @@ extern "C" {
 int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_value, uint64_t n, const float view[16],
                         const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h,
                         uint64_t *d_packed, int32_t accumulate, uint32_t index_base, float *d_depth, uint32_t *d_id) {
-	if (!ctx || !view || !proj || (n && (!d_xyz || !d_value))) return set_err(TREEE_ERR_INVALID, "treee_splat_dev: null argument");
+	if (!ctx || !view || !proj || (n && !d_xyz)) return set_err(TREEE_ERR_INVALID, "treee_splat_dev: null argument");
+	if (n && !d_value && (vmin != 0u || vmax != 0xFFFFFFFFu || d_id))
+		return set_err(TREEE_ERR_INVALID, "treee_splat_dev: d_value may only be null when nothing is culled (vmin = 0, vmax = u32::MAX) and no id buffer is asked for");
 	if (w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 31)) return set_err(TREEE_ERR_INVALID, "bad framebuffer size %ux%u", w, h);
 	if (n >= 0xFFFFFFFFull - index_base) return set_err(TREEE_ERR_UNSUPPORTED, "point index does not fit in 32 bits");
 	if (index_base != 0 && d_id)

@@ -259,6 +259,21 @@ def reduce_packed_min(packed, group=None):
     return _all_reduce(packed, dist.ReduceOp.MIN, group)
 
 
+class _Done:
+    def wait(self):
+        return None
+
+
+def reduce_packed_min_async(packed, group=None):
+    """`reduce_packed_min` as an asynchronous collective: RCCL runs it on the process group's own stream while the
+    caller's stream keeps computing; `.wait()` makes the current stream wait for it.  (gloo rehearsal: host-staged,
+    synchronous.)"""
+    if packed.is_cuda and _host_staged(group):
+        _all_reduce(packed, dist.ReduceOp.MIN, group)
+        return _Done()
+    return dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group, async_op=True)
+
+
 def partition_segments(counts, world):
     """SURVEY 8 E, first form: the reference's kNN units are whole segments (one KD-tree per segment,
     calculations.rs:97-118), so they shard with no exchange at all.  Greedy longest-processing-time assignment of
