@@ -481,6 +481,9 @@ template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef TREEE_NG
+#define TREEE_NG 4
+#endif
 #ifndef TREEE_ORDER_RANGE
 #define TREEE_ORDER_RANGE 128
 #endif
@@ -686,10 +689,12 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 	// Query box of the wave and its largest threshold bound every lane's search ball, so a node
 	// whose box is farther than that from the query box cannot matter to any lane.  Seeds are the
 	// sibling subtrees along the path from the own bucket to the root (an exact cover).
-	// Query boxes: one per group of 8 consecutive lanes (Morton-adjacent queries), each with the
-	// largest threshold of its lanes.  A single box for the whole wave is far too loose when the
-	// bucket straddles a jump of the Morton curve.  The boxes live in the (idle) tile memory.
-	constexpr int NG = 8;
+	// Query boxes: one per group of GL consecutive lanes (Morton-adjacent queries), each with the
+	// largest threshold of its lanes.  Measured at 15 M points (the kernel is VALU-issue bound, a sub-box costs
+	// ~14 VALU per tested node): 16 boxes 12.19 ms, 8: 11.85, 4: 11.53, 2: 11.53, 1: 11.45 -- but a single box lists
+	// 58 buckets per wave instead of 50 and overflows the list 1.5x as often, so 4 is the default.  The boxes
+	// live in the (idle) tile memory.
+	constexpr int NG = TREEE_NG, GL = 64 / NG; // sub-boxes per wave, lanes per sub-box
 	float *gbox = &tile[0][0]; // [NG][8]: lo.xyz, tau bits, hi.xyz, pad
 	{
 		const float q[3] = {qx, qy, qz};
@@ -698,7 +703,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 		for (int c = 0; c < 3; ++c) {
 			float lo = live ? q[c] : INFINITY, hi = live ? q[c] : -INFINITY;
 #pragma unroll
-			for (int o = 4; o > 0; o >>= 1) {
+			for (int o = GL / 2; o > 0; o >>= 1) {
 				lo = fminf(lo, __shfl_xor(lo, o, 64));
 				hi = fmaxf(hi, __shfl_xor(hi, o, 64));
 			}
@@ -707,12 +712,12 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 		}
 		uint32_t gtau = live ? thr : 0u;
 #pragma unroll
-		for (int o = 4; o > 0; o >>= 1) {
+		for (int o = GL / 2; o > 0; o >>= 1) {
 			const uint32_t t = __shfl_xor(gtau, o, 64);
 			gtau = t > gtau ? t : gtau;
 		}
-		if ((lane & 7) == 0) {
-			float *g = gbox + (lane >> 3) * 8;
+		if ((lane & (GL - 1)) == 0) {
+			float *g = gbox + (lane / GL) * 8;
 			g[0] = glo[0];
 			g[1] = glo[1];
 			g[2] = glo[2];
