@@ -481,6 +481,9 @@ template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef TREEE_NBR
+#define TREEE_NBR 4 // Morton neighbours of the own bucket scanned before the tree walk (start-1, start+1, start-2, start+2); measured 0: 16.8 ms, 1: 12.8, 2: 11.6, 4: 11.5
+#endif
 #ifndef TREEE_NG
 #define TREEE_NG 4
 #endif
@@ -645,14 +648,19 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 	};
 
 	if (start >= a.nb) start = a.nb - 1;
+	// buckets start-1, start+1, start-2, ... (TREEE_NBR of them) are scanned right after the own one
+	auto prescanned = [&](uint32_t b) __attribute__((always_inline)) -> bool {
+		const uint32_t below = start - b, above = b - start; // one of them wraps to a huge value
+		return (below >= 1u && below <= (uint32_t)((TREEE_NBR + 1) / 2)) || (above >= 1u && above <= (uint32_t)(TREEE_NBR / 2));
+	};
 	uint32_t myseg = 0u; // wave-uniform: a bucket belongs to one segment
 	if constexpr (SEG) myseg = __float_as_uint(a.bvh[2ull * (a.P + start)].w);
 	// Own bucket, then its two neighbours in Morton order.  When a bucket straddles a jump of the
 	// curve, the lanes on its minority side find their real neighbours in the adjacent bucket; without
 	// it their threshold (and with it the wave's candidate list) would be enormous.
 #pragma unroll 1
-	for (int t = 0; t < 3; ++t) {
-		const uint32_t b = t == 0 ? start : (t == 1 ? start - 1u : start + 1u); // start-1 wraps to a huge value at 0
+	for (int t = 0; t < 1 + TREEE_NBR; ++t) {
+		const uint32_t b = t == 0 ? start : ((t & 1) ? start - (uint32_t)((t + 1) >> 1) : start + (uint32_t)(t >> 1)); // below 0 wraps to a huge value
 		if (b >= a.nb) continue;
 		if constexpr (SEG) {
 			if (t > 0 && __float_as_uint(a.bvh[2ull * (a.P + b)].w) != myseg) continue; // Morton neighbour of another segment
@@ -760,7 +768,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 			hit = hit && valid;
 			if constexpr (SEG) hit = hit && myseg >= __float_as_uint(lo.w) && myseg <= __float_as_uint(hi.w);
 			// the own bucket's Morton neighbours were scanned above (the own bucket is no seed's descendant)
-			const bool leafhit = hit && node >= a.P && (node - a.P) < a.nb && node - a.P != start - 1u && node - a.P != start + 1u;
+			const bool leafhit = hit && node >= a.P && (node - a.P) < a.nb && !prescanned(node - a.P);
 			const bool innerhit = hit && node < a.P;
 			// 4-ary step: a hit inner node expands straight to its four grandchildren (contiguous in the
 			// implicit layout) when they exist, which halves the number of dependent BFS rounds
@@ -919,7 +927,7 @@ template <bool DIAG, bool SEG> __global__ __launch_bounds__(64, TREEE_KNN_WAVES)
 					i = 2u * i;
 					continue;
 				}
-				if (hit && i - a.P != start - 1u && i - a.P != start + 1u) { // the neighbours were scanned above
+				if (hit && !prescanned(i - a.P)) { // the neighbours were scanned above
 					scan_bucket(i - a.P);
 					ST(st_buckets++);
 				}
