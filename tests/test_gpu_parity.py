@@ -609,6 +609,101 @@ def test_knn_crowded_morton_cells(T, oracle):
     assert np.array_equal(sd[:3000].cpu().numpy().view(np.uint32), rb_ent["distance"].view(np.uint32))
 
 
+def _fuzz_cloud(rng, n, kind):
+    if kind == "uniform":
+        p = rng.random((n, 3)) * rng.choice([1.0, 50.0, 1000.0])
+    elif kind == "clusters":
+        c = rng.random((max(1, n // 200), 3)) * 100
+        p = c[rng.integers(0, len(c), n)] + rng.standard_normal((n, 3)) * rng.choice([0.01, 1.0])
+    elif kind == "line":
+        t = rng.random((n, 1)) * 100
+        p = t * np.array([[1.0, 0.5, -2.0]]) + rng.standard_normal((n, 3)) * 1e-3
+    elif kind == "plane_grid":
+        p = np.stack([rng.integers(0, 60, n), np.zeros(n), rng.integers(0, 60, n)], 1) * 0.25
+    elif kind == "duplicates":
+        base = rng.random((max(1, n // 50), 3)) * 10
+        p = base[rng.integers(0, len(base), n)]
+    else:  # two scales: a dense blob inside a sparse halo
+        p = rng.standard_normal((n, 3)) * 20
+        p[: n // 2] *= 1e-3
+    return np.ascontiguousarray(p, dtype=np.float32)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_knn_fuzz_vs_brute_force(T, seed):
+    """random sizes, shapes, k and radii against an exact brute force (same op order, computed with torch on the
+    GPU): distances bit-identical, counts equal, indices valid members of their distance group"""
+    import torch
+
+    rng = np.random.default_rng(1000 + seed)
+    kinds = ["uniform", "clusters", "line", "plane_grid", "duplicates", "two_scales"]
+    for trial in range(6):
+        kind = kinds[(seed + trial) % len(kinds)]
+        n = int(rng.choice([1, 2, 63, 64, 65, 300, 4097, 20_000]))
+        k = int(rng.choice([1, 5, 31, 32]))
+        pts = _fuzz_cloud(rng, n, kind)
+        d_pts = torch.from_numpy(pts).cuda()
+        tree = T.KDTree.new(d_pts)
+        nq = min(n, 3000)
+        q = d_pts[torch.from_numpy(rng.choice(n, nq, replace=False)).cuda()] if n > 1 else d_pts
+        # brute force, metric.rs:21-26 op order, elementwise torch kernels (no contraction across kernels)
+        dx = q[:, None, 0] - d_pts[None, :, 0]
+        dy = q[:, None, 1] - d_pts[None, :, 1]
+        dz = q[:, None, 2] - d_pts[None, :, 2]
+        dist = (dx * dx + dy * dy) + dz * dz
+        kk = min(k, n)
+        ref = torch.sort(torch.topk(dist, kk, dim=1, largest=False).values, dim=1).values
+        for maxd in (F32_MAX, float(ref[:, kk // 2].median().item()) + 1e-12):
+            d, i, c = tree.k_nearest_dev(q, k, maxd)
+            want_c = (ref < maxd).sum(1).to(c.dtype)
+            assert torch.equal(c, want_c), (kind, n, k, maxd)
+            valid = torch.arange(k, device="cuda")[None, :] < c[:, None]
+            got = d[:, :kk]
+            assert torch.equal(got[valid[:, :kk]].view(torch.int32), ref[valid[:, :kk]].view(torch.int32)), (kind, n, k, maxd)
+            idx = i.long().clamp(min=0)
+            back = torch.gather(dist, 1, idx[:, :kk])
+            assert torch.equal(back[valid[:, :kk]].view(torch.int32), got[valid[:, :kk]].view(torch.int32)), (kind, n, k)
+            # no index twice in a row
+            srt = torch.sort(torch.where(valid[:, :kk], idx[:, :kk], torch.arange(kk, device="cuda")[None, :] + n), dim=1).values
+            assert bool((srt[:, 1:] != srt[:, :-1]).all()) or kk == 1
+        tree.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_segmented_knn_fuzz_vs_brute_force(T, seed):
+    """the segmented structure against a brute force that masks other segments"""
+    import torch
+
+    rng = np.random.default_rng(2000 + seed)
+    kinds = ["uniform", "clusters", "plane_grid", "duplicates", "two_scales", "line"]
+    for trial in range(5):
+        kind = kinds[(seed + trial) % len(kinds)]
+        n = int(rng.choice([2, 64, 65, 129, 1000, 6000]))
+        nseg = int(rng.choice([1, 2, 7, 60]))
+        k = int(rng.choice([1, 8, 31]))
+        pts = _fuzz_cloud(rng, n, kind)
+        seg = rng.integers(0, nseg, n).astype(np.int32)
+        if trial % 2:
+            seg = np.sort(seg)  # contiguous segments as the reference stores them
+        d_pts, d_seg = torch.from_numpy(pts).cuda(), torch.from_numpy(seg).cuda()
+        tree = T.KDTree.new_segments(d_pts, d_seg, nseg)
+        d, i, c = tree.self_neighbors_dev(k)
+        dx = d_pts[:, None, 0] - d_pts[None, :, 0]
+        dy = d_pts[:, None, 1] - d_pts[None, :, 1]
+        dz = d_pts[:, None, 2] - d_pts[None, :, 2]
+        dist = (dx * dx + dy * dy) + dz * dz
+        dist = torch.where(d_seg[:, None] == d_seg[None, :], dist, torch.full_like(dist, float("inf")))
+        kk = min(k, n)
+        ref = torch.sort(torch.topk(dist, kk, dim=1, largest=False).values, dim=1).values
+        want_c = (ref < F32_MAX).sum(1).to(c.dtype)
+        assert torch.equal(c, want_c), (kind, n, nseg, k)
+        valid = torch.arange(k, device="cuda")[None, :] < c[:, None]
+        assert torch.equal(d[:, :kk][valid[:, :kk]].view(torch.int32), ref[valid[:, :kk]].view(torch.int32)), (kind, n, nseg, k)
+        idx = i.long().clamp(min=0)
+        assert bool(((d_seg[idx] == d_seg[:, None]) | ~valid).all())
+        tree.close()
+
+
 def test_knn_nan_inf_and_extreme_inputs(T, oracle):
     rng = np.random.default_rng(21)
     pts = (rng.random((5000, 3)) * 20).astype(np.float32)
