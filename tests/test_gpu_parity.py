@@ -312,6 +312,30 @@ def test_splat_bit_exact_vs_software_rasteriser(T, oracle, scale, transform):
     assert (depth < 1.0).sum() > 100
 
 
+@pytest.mark.parametrize("seed", range(5))
+def test_splat_fuzz_vs_software_rasteriser(T, oracle, seed):
+    """random cameras (position, pitch, yaw), splat scales, value ranges and frame sizes; depth + id bit-exact"""
+    from treee_amd import synth
+
+    rng = np.random.default_rng(3000 + seed)
+    pts, seg = synth.forest_cloud(int(rng.choice([1, 777, 40_000])), plot=float(rng.choice([8.0, 30.0])))
+    val = rng.integers(0, 2**32, len(pts), dtype=np.uint64).astype(np.uint32)
+    for _ in range(4):
+        w, h = int(rng.integers(5, 200)), int(rng.integers(5, 120))
+        cam = T.Camera3D(w / h)
+        cy, sy = np.cos(rng.uniform(0, 6.28)), np.sin(rng.uniform(0, 6.28))
+        yaw = np.array([[cy, 0, sy, 0], [0, 1, 0, 0], [-sy, 0, cy, 0], [0, 0, 0, 1]], np.float32)
+        tf = yaw @ T.rotation_x(float(rng.uniform(-1.5, 0.3))) @ T.translation(float(rng.uniform(-5, 5)), float(rng.uniform(-2, 10)), float(rng.uniform(0.5, 80)))
+        view, proj = T.view_from_transform(tf.astype(np.float32)), cam.projection()
+        scale = float(rng.choice([0.01, 0.1, 0.7, 3.0]))
+        vmin, vmax = (0, 0xFFFFFFFF) if rng.random() < 0.5 else (int(rng.integers(0, 2**31)), int(rng.integers(2**31, 2**32)))
+        env = T.PointCloudEnvironment(vmin, vmax, scale)
+        depth, ids = T.PointCloud(pts).render(T.PointCloudProperty(val), view, proj, env, w, h)
+        rd, ri, _ = oracle.splat(pts, val, view, proj, scale, vmin, vmax, w, h)
+        assert np.array_equal(depth.view(np.uint32), rd.view(np.uint32)), (w, h, scale)
+        assert np.array_equal(ids, ri), (w, h, scale)
+
+
 def test_splat_value_cull_ties_and_device_path(T, oracle):
     import torch
 
