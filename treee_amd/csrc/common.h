@@ -122,8 +122,10 @@ int32_t bbox_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, float corner_ou
                  float *size_out); // synchronises
 int32_t gather_sorted_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_perm, uint64_t n,
                           float4 *d_sorted);
+// d_live (device, optional): number of leading elements that matter -- the rest of d_in is taken as zero and the
+// rest of d_out is left unwritten (capacity-sized arrays of the octree levels)
 int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n,
-                               uint32_t *d_total /* device, optional */);
+                               uint32_t *d_total /* device, optional */, const uint32_t *d_live = nullptr);
 
 // persistent device blocks for handles: taken from / returned to the owning context's pool.
 // pool_release tolerates a context that has already been destroyed (falls back to hipFree).

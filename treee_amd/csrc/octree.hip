@@ -186,7 +186,7 @@ int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 		const uint32_t grid = div_up((uint64_t)cap * 8, 256);
 		hipLaunchKernelGGL(k_oct_split, dim3(grid), dim3(256), 0, st, o->sc->d_keys, o->d_nodes, d_lvl + 2 * level, cap, o->leaf_cap, d_cnt, d_bounds);
 		TREEE_LAUNCH_CHECK();
-		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_cnt, d_off, cap, d_total));
+		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_cnt, d_off, cap, d_total, d_lvl + 2 * level + 1)); // only the level's nodes
 		hipLaunchKernelGGL(k_oct_emit, dim3(grid), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * level, d_off, d_bounds, d_total);
 		TREEE_LAUNCH_CHECK();
 	}

@@ -459,8 +459,16 @@ int32_t sort_pairs_dev(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t
 constexpr int SC_ITEMS = 4;
 constexpr int SC_TILE = 256 * SC_ITEMS;
 
-__global__ __launch_bounds__(256) void sc_reduce(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ sums) {
+// `live` (optional, device): only the first *live elements are non-zero / wanted; blocks past them do nothing
+__global__ __launch_bounds__(256) void sc_reduce(const uint32_t *__restrict__ in, uint32_t n, uint32_t *__restrict__ sums, const uint32_t *__restrict__ live) {
 	__shared__ uint32_t part[4];
+	if (live) {
+		n = min(n, *live);
+		if (blockIdx.x * SC_TILE >= n) {
+			if (threadIdx.x == 0) sums[blockIdx.x] = 0u;
+			return;
+		}
+	}
 	uint32_t i0 = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS, s = 0;
 #pragma unroll
 	for (int j = 0; j < SC_ITEMS; ++j) s += (i0 + j < n) ? in[i0 + j] : 0u;
@@ -481,8 +489,13 @@ __global__ __launch_bounds__(256) void sc_scan_sums(uint32_t *__restrict__ sums,
 	if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
-__global__ __launch_bounds__(256) void sc_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ sums) {
+__global__ __launch_bounds__(256) void sc_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n, const uint32_t *__restrict__ sums,
+                                                 const uint32_t *__restrict__ live) {
 	__shared__ uint32_t part[4];
+	if (live) {
+		n = min(n, *live);
+		if (blockIdx.x * SC_TILE >= n) return;
+	}
 	uint32_t i0 = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS, v[SC_ITEMS], s = 0;
 #pragma unroll
 	for (int j = 0; j < SC_ITEMS; ++j) {
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(256) void sc_apply(const uint32_t *__restrict__ in,
 	}
 }
 
-int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_total) {
+int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_total, const uint32_t *d_live) {
 	if (n == 0) {
 		if (d_total) TREEE_HIP(hipMemsetAsync(d_total, 0, 4, ctx->stream));
 		return TREEE_OK;
@@ -505,9 +518,9 @@ int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d
 	uint32_t nb = div_up(n, SC_TILE);
 	uint32_t *d_sums = nullptr;
 	TREEE_TRY(ctx->alloc_t(nb, &d_sums));
-	hipLaunchKernelGGL(sc_reduce, dim3(nb), dim3(256), 0, ctx->stream, d_in, (uint32_t)n, d_sums);
+	hipLaunchKernelGGL(sc_reduce, dim3(nb), dim3(256), 0, ctx->stream, d_in, (uint32_t)n, d_sums, d_live);
 	hipLaunchKernelGGL(sc_scan_sums, dim3(1), dim3(256), 0, ctx->stream, d_sums, nb, d_total);
-	hipLaunchKernelGGL(sc_apply, dim3(nb), dim3(256), 0, ctx->stream, d_in, d_out, (uint32_t)n, d_sums);
+	hipLaunchKernelGGL(sc_apply, dim3(nb), dim3(256), 0, ctx->stream, d_in, d_out, (uint32_t)n, d_sums, d_live);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
 }
@@ -537,14 +550,18 @@ void SortedCloud::release() {
 	d_sorted = nullptr;
 }
 
+// every LONG_RUN_STEP-th position is probed: a run longer than LONG_RUN + LONG_RUN_STEP is always found, one
+// between LONG_RUN and that may or may not be (the threshold is a heuristic, the probe a 64th of the reads)
+constexpr uint32_t LONG_RUN_STEP = 64;
 __global__ __launch_bounds__(256) void k_long_run(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ flag) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const uint64_t i = (uint64_t)(blockIdx.x * 256u + threadIdx.x) * LONG_RUN_STEP;
 	if (i + LONG_RUN < n && keys[i] == keys[i + LONG_RUN]) *flag = 1u; // benign race: every writer stores 1
 }
 
 int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t *d_flag) {
 	TREEE_HIP(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
-	if (n > LONG_RUN) hipLaunchKernelGGL(k_long_run, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_keys, (uint32_t)n, d_flag);
+	if (n > LONG_RUN)
+		hipLaunchKernelGGL(k_long_run, dim3(div_up(div_up(n, LONG_RUN_STEP), 256)), dim3(256), 0, ctx->stream, d_keys, (uint32_t)n, d_flag);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
 }
