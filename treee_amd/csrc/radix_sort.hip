@@ -130,10 +130,22 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist(const uint32_t *__restrict__
 	for (int i = 0; i < 4; ++i) h[i][tid] = 0;
 	__syncthreads();
 	const uint32_t base = blockIdx.x * RS_TILE;
+	if (base + RS_TILE <= n) { // full tile: 16-byte loads (the order inside the tile does not matter for a histogram)
+		const uint4 *k4 = (const uint4 *)(keys + base);
 #pragma unroll
-	for (int i = 0; i < RS_ITEMS; ++i) {
-		uint32_t idx = base + i * RS_BLOCK + tid;
-		if (idx < n) atomicAdd(&h[w][(keys[idx] >> shift) & 255u], 1u);
+		for (int i = 0; i < RS_ITEMS / 4; ++i) {
+			const uint4 k = k4[i * RS_BLOCK + tid];
+			atomicAdd(&h[w][(k.x >> shift) & 255u], 1u);
+			atomicAdd(&h[w][(k.y >> shift) & 255u], 1u);
+			atomicAdd(&h[w][(k.z >> shift) & 255u], 1u);
+			atomicAdd(&h[w][(k.w >> shift) & 255u], 1u);
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < RS_ITEMS; ++i) {
+			uint32_t idx = base + i * RS_BLOCK + tid;
+			if (idx < n) atomicAdd(&h[w][(keys[idx] >> shift) & 255u], 1u);
+		}
 	}
 	__syncthreads();
 	table[(uint32_t)tid * ntiles + blockIdx.x] = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
