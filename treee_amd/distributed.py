@@ -271,7 +271,11 @@ def reduce_packed_min_async(packed, group=None):
     if packed.is_cuda and _host_staged(group):
         _all_reduce(packed, dist.ReduceOp.MIN, group)
         return _Done()
-    return dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group, async_op=True)
+    try:
+        return dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group, async_op=True)
+    except (RuntimeError, NotImplementedError):  # a backend without asynchronous collectives: do it in line
+        dist.all_reduce(packed, op=dist.ReduceOp.MIN, group=group)
+        return _Done()
 
 
 def partition_segments(counts, world):
