@@ -101,7 +101,10 @@ def _ghost_worker(rank, world, port, out_dir):
     packed = torch.full((4, 4), (0x3F800000 << 32) | 0xFFFFFFFF, dtype=torch.int64)
     packed[rank, rank] = (0x3F000000 << 32) | (rank * n + 5)
     packed[3, 3] = ((0x3E000000 + rank) << 32) | rank
+    packed_async = packed.clone()
     D.reduce_packed_min(packed)
+    D.reduce_packed_min_async(packed_async).wait()  # the overlapped form used by the multi-GPU step
+    assert torch.equal(packed, packed_async)
     torch.save({"pts": pts, "ghosts": ghosts, "ok": ok, "bad": bad, "packed": packed}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
