@@ -563,7 +563,7 @@ def test_tile_stream_equals_tile_by_tile(T, oracle, knn_k):
 
 
 # ---------------------------------------------------------------- kNN edge cases (sorted-32 kernel paths)
-@pytest.mark.parametrize("k", [1, 2, 7, 15, 16, 17, 31, 32, 33])
+@pytest.mark.parametrize("k", [1, 2, 7, 15, 16, 17, 31, 32, 33, 48, 64, 65])
 def test_knn_every_small_k(T, oracle, k):
     pts = quantised_cloud(6000, 300 + k, extent=(12, 4, 12))
     r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts[:1500], k, F32_MAX)

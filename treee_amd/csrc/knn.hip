@@ -509,7 +509,7 @@ constexpr int FRONT_CAP = TREEE_FRONT_CAP; // BFS frontier; the default aliases 
 // SEG: the cloud is segmented (build_segmented) -- records are padded with (NaN, NaN, NaN, ~0u) so that no bucket
 // straddles a segment, tree nodes carry the range of segments below them, and a query only descends into / scans
 // nodes and buckets of its own segment: the result is what one KD-tree per segment returns (calculations.rs:329).
-template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, TREEE_KNN_WAVES) void k_knn_sorted32(KnnArgs a) {
+template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SKT <= 32 ? TREEE_KNN_WAVES : 2) void k_knn_sorted32(KnnArgs a) {
 	constexpr int SK = SKT; // list length of this instantiation: 32 (k <= 32) or 16 (k <= 16: half the list registers and merge work, no spills)
 	__shared__ __attribute__((aligned(16))) float tile[3][BUCKET]; // SoA candidate tile (x[], y[], z[])
 	__shared__ uint32_t buf[2 * SBUF * 64]; // [pos | distance bits][slot][lane]: conflict-free per slot
@@ -1114,7 +1114,11 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		a.q_start = d_qs;
 	}
 	static const bool force_heap = getenv("TREEE_KNN_FORCE_HEAP") != nullptr; // A/B and test hook
-	if (k <= (uint32_t)SK && !force_heap) {
+	static const bool no64 = getenv("TREEE_KNN_NO_K64") != nullptr; // A/B and test hook
+	if (k > (uint32_t)SK && k <= 64u && !force_heap && !no64 && !t->segmented) {
+		if (a.wave_order && !d_q) nwaves = t->n_order;
+		hipLaunchKernelGGL((k_knn_sorted32<false, false, 64>), dim3(nwaves), dim3(64), 0, ctx->stream, a); // 64-entry list, 2 waves/SIMD
+	} else if (k <= (uint32_t)SK && !force_heap) {
 		if (a.wave_order && !d_q) nwaves = t->n_order; // padded dispatch table
 		static const bool no16 = getenv("TREEE_KNN_NO_K16") != nullptr; // A/B and test hook
 		if (k <= 16u && !no16 && !a.stats) {
