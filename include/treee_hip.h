@@ -90,7 +90,9 @@ int32_t treee_knn_len(const treee_knn *t, uint64_t *n_out);
  * number of valid entries; out[i*k .. i*k+counts[i]) ascending by distance, all distance <
  * max_dist_sq (strict, squared).  Tie rule: distances and counts are
  * bit-identical to the reference; among equal distances the entry with the smaller
- * (morton key, index) wins.  k == 0 -> TREEE_ERR_INVALID (reference panics). */
+ * (morton key, index) wins.  k == 0 -> TREEE_ERR_INVALID (reference panics).
+ * k <= 16, <= 32 and <= 64 run register-resident lists of that length (the reference uses 31);
+ * 64 < k <= 319 runs an LDS-heap kernel; larger k -> TREEE_ERR_UNSUPPORTED. */
 int32_t treee_knn_query_batch(const treee_knn *t, const float *q_xyz, uint64_t nq, uint32_t k,
                               float max_dist_sq, treee_entry *out, uint32_t *counts);
 /* device form: SoA outputs d_dist[nq*k] f32, d_index[nq*k] u32 (0xFFFFFFFF unused),
