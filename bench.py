@@ -139,7 +139,8 @@ def main():
             pending = stages.run("splat", draw, record)
         tree = stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
         cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
-        stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv), record)
+        # at N > 1 only the shard's own points are queried: the ghosts behind them are neighbours, not queries
+        stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv, n_own=n if world > 1 else None), record)
         val = stages.run("map_to_u32", lambda: T.map_to_u32_dev(cv[:n], ctx), record)
 
         def splat():
@@ -204,7 +205,7 @@ def main():
         total_points = n * world * args.steps
         value = total_points / elapsed / 1e6
         knn_ms = ms["knn_curve"]
-        m_knn = state["cloud_n"]
+        m_knn = n  # queries per launch (at N > 1 the ghosts behind the own points are neighbours only)
         achieved = BYTES["knn_curve"] * m_knn / (knn_ms * 1e-3) / 1e9
         stage_roof = {}
         for name, b in BYTES.items():

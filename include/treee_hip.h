@@ -121,6 +121,10 @@ int32_t treee_curvature(const float *xyz_aos, uint64_t n, uint32_t k, float max_
                         float *curve_out);
 int32_t treee_curvature_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
                             float *d_curve_out);
+/* the same, but only points whose original index is < n_own are queried; the rest (a shard's ghost points,
+ * appended behind its own points) only serve as neighbours.  d_curve_out needs n_own entries. */
+int32_t treee_curvature_own_dev(treee_ctx *ctx, const treee_knn *t, uint64_t n_own, uint32_t k,
+                                float max_dist_sq, float *d_curve_out);
 /* the same loop run for every segment of a segmented cloud in one pass: curve_out[i] is what
  * SegmentInformation::update(calc_curve = true) computes for point i inside its own segment
  * (calculations.rs:328-373 called per segment, interactive/mod.rs:224-231) */

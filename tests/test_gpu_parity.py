@@ -201,6 +201,26 @@ def test_curvature_vs_oracle(T, oracle):
     assert np.mean(np.abs(got[~nan] - ref[~nan]) < 1e-5) > 0.999
 
 
+def test_curvature_of_own_points_only(T):
+    """a shard queries its own points only; the ghost points appended behind them still count as neighbours"""
+    import torch
+
+    from treee_amd import synth
+
+    pts, _ = synth.forest_cloud_torch(300_000, "cuda", plot=30.0)
+    n_own = 250_001
+    tree = T.KDTree.new(pts)
+    full = tree.curvature_dev(31)
+    own = torch.full((n_own,), -7.0, dtype=torch.float32, device="cuda")
+    tree.curvature_dev(31, out=own, n_own=n_own)
+    torch.cuda.synchronize()
+    assert torch.equal(own.view(torch.int32), full[:n_own].view(torch.int32))
+    for k in (8, 40):  # the 16- and 64-entry instantiations
+        a = tree.curvature_dev(k)
+        b = tree.curvature_dev(k, n_own=n_own)
+        assert torch.equal(a[:n_own].view(torch.int32), b.view(torch.int32))
+
+
 def test_curvature_tie_free_cloud_tight_tolerance(T, oracle):
     rng = np.random.default_rng(9)
     pts = rng.random((20_000, 3)).astype(np.float32) * np.float32(25)  # full-mantissa: no distance ties

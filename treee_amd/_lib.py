@@ -62,6 +62,7 @@ SYMBOLS = {
     "treee_curvature": (_i32, [_vp, _u64, _u32, _f32, _vp]),
     "treee_curvature_segments": (_i32, [_vp, _vp, _u64, _u32, _u32, _f32, _vp]),
     "treee_curvature_dev": (_i32, [_vp, _vp, _u32, _f32, _vp]),
+    "treee_curvature_own_dev": (_i32, [_vp, _vp, _u64, _u32, _f32, _vp]),
     "treee_map_to_u32_dev": (_i32, [_vp, _vp, _u64, _vp]),
     "treee_sort_build": (_i32, [_vp, _u64, _vp, _f32, _u32, _u32, _pp]),
     "treee_sort_build_dev": (_i32, [_vp, _vp, _u64, _vp, _f32, _u32, _u32, _pp]),

@@ -207,6 +207,7 @@ struct KnnArgs {
 	const uint32_t *q_start;     // per wave: start bucket
 	const uint32_t *wave_order;  // self mode: bucket handled by workgroup i (largest boxes first), or null
 	uint32_t nq;
+	uint32_t q_limit; // self mode: only points with original index < q_limit are queried (the rest are neighbours only)
 	uint32_t k, maxbits;
 	float *out_dist;
 	uint32_t *out_index;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64) void k_knn_heap(KnnArgs a) {
 	h.lane = lane;
 
 	const uint32_t slot = blockIdx.x * 64u + lane;
-	const bool live = slot < a.nq;
+	bool live = slot < a.nq;
 	float qx = 0.0f, qy = 0.0f, qz = 0.0f;
 	uint32_t row = 0, start;
 	if (a.q_xyz) {
@@ -247,8 +248,10 @@ __global__ __launch_bounds__(64) void k_knn_heap(KnnArgs a) {
 			qy = p.y;
 			qz = p.z;
 			row = __float_as_uint(p.w);
+			live = row < a.q_limit;
 		}
 		start = blockIdx.x;
+		if (!__any(live)) return; // before any barrier: the whole single-wave workgroup leaves
 	}
 	for (int s = 0; s < h.k; ++s) { // FixedSet::new (best_set.rs:20-28)
 		h.D(s) = a.maxbits;
@@ -544,12 +547,10 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 			qy = p.y;
 			qz = p.z;
 			row = __float_as_uint(p.w);
-			if constexpr (SEG) live = row != ~0u; // padding record
+			live = row < a.q_limit; // (a padding record of a segmented cloud carries ~0u; ghosts sit behind the own points)
 		}
 		start = wave_id;
-	}
-	if constexpr (SEG) {
-		if (!__any(live)) return; // a bucket of padding only (the tail of the padded array)
+		if (!__any(live)) return; // a bucket of padding or of neighbour-only points
 	}
 	// dead lanes never pass the filter: NaN query -> NaN distance
 	if (!live) qx = __uint_as_float(0x7FC00000u);
@@ -1065,7 +1066,7 @@ uint32_t max_bits(float max_dist_sq) {
 }
 
 int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_t nq, uint32_t k, float max_dist_sq,
-                   float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve) {
+                   float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit = ~0ull) {
 	if (k == 0) return set_err(TREEE_ERR_INVALID, "k == 0 (the reference panics at best_set.rs:74)");
 	if (nq == 0) return TREEE_OK;
 	if (nq >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "nq too large");
@@ -1093,6 +1094,7 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 	a.stats = nullptr;
 	a.thr_io = nullptr;
 	a.thr_seed = 0;
+	a.q_limit = q_limit >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)q_limit;
 	static const bool want_stats = getenv("TREEE_KNN_STATS") != nullptr; // diagnostic counters
 	if (want_stats && !t->segmented) {
 		TREEE_TRY(ctx->alloc_t(64, &a.stats));
@@ -1586,6 +1588,13 @@ int32_t treee_knn_self_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
 	return launch_knn(ctx, t, nullptr, t->sc->n, k, max_dist_sq, d_dist, d_index, d_counts, nullptr);
+}
+
+int32_t treee_curvature_own_dev(treee_ctx *ctx, const treee_knn *t, uint64_t n_own, uint32_t k, float max_dist_sq, float *d_curve) {
+	if (!ctx || !t || !d_curve) return set_err(TREEE_ERR_INVALID, "treee_curvature_own_dev: null argument");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	return launch_knn(ctx, t, nullptr, t->sc->n, k, max_dist_sq, nullptr, nullptr, nullptr, d_curve, n_own);
 }
 
 int32_t treee_curvature_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq, float *d_curve) {

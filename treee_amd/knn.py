@@ -153,13 +153,19 @@ class KDTree:
         _lib.check(_lib.lib().treee_knn_self_dev(c.handle, self._h, k, max_distance, ptr(dist), ptr(index), ptr(counts)))
         return dist, index, counts
 
-    def curvature_dev(self, k=31, max_distance=F32_MAX, ctx=None, out=None):
+    def curvature_dev(self, k=31, max_distance=F32_MAX, ctx=None, out=None, n_own=None):
+        """`n_own`: only the first n_own points (original order) are queried -- a shard's ghost points behind them
+        serve as neighbours only."""
         import torch
 
         c = self._ctx(ctx)
         if out is None:
-            out = torch.empty((self.n,), dtype=torch.float32, device=c.device)
-        _lib.check(_lib.lib().treee_curvature_dev(c.handle, self._h, k, max_distance, ptr(out)))
+            out = torch.empty((self.n if n_own is None else n_own,), dtype=torch.float32, device=c.device)
+        if n_own is None:
+            _lib.check(_lib.lib().treee_curvature_dev(c.handle, self._h, k, max_distance, ptr(out)))
+        else:
+            assert out.numel() >= n_own
+            _lib.check(_lib.lib().treee_curvature_own_dev(c.handle, self._h, int(n_own), k, max_distance, ptr(out)))
         return out
 
 
