@@ -2,8 +2,9 @@
 // compaction of the points whose (x, z) lies inside a `keep` box and outside a `drop` box.
 //   boundary points of a tile  = keep: everything,      drop: the tile shrunk by the halo on shared faces
 //   ghosts received from peers = keep: the dilated tile, drop: nothing   (NaN padding never passes)
-// One flag pass, one exclusive scan, one scatter: 3 launches instead of ~15 elementwise torch kernels,
-// and the output keeps the input order (deterministic ghost indices).  No reference counterpart: the
+// A count pass per 4096-point tile, a scan of the tile counts and a write pass that re-evaluates the predicate: the cloud
+// is read twice and nothing per point is stored in between; the output keeps the input order (deterministic ghost
+// indices).  No reference counterpart: the
 // reference is a single-process program.
 #include "common.h"
 
@@ -17,22 +18,67 @@ struct Box2 {
 
 __device__ __forceinline__ bool in_box(const Box2 &b, float x, float z) { return x >= b.x0 && x < b.x1 && z >= b.z0 && z < b.z1; }
 
-__global__ __launch_bounds__(256) void k_select_flag(const float *__restrict__ xyz, uint32_t n, Box2 keep, Box2 drop, uint32_t *__restrict__ flag) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n) return;
-	const float x = xyz[3ull * i + 0], z = xyz[3ull * i + 2];
-	flag[i] = (in_box(keep, x, z) && !in_box(drop, x, z)) ? 1u : 0u;
+constexpr int SEL_ITEMS = 16, SEL_TILE = 256 * SEL_ITEMS; // points per workgroup
+
+// pass 1: matches per tile (the predicate is cheap, so it is evaluated again in pass 2 instead of storing 60 MB of flags)
+__global__ __launch_bounds__(256) void k_select_count(const float *__restrict__ xyz, uint32_t n, Box2 keep, Box2 drop, uint32_t *__restrict__ tile_count) {
+	__shared__ uint32_t s_w[4];
+	const uint32_t base = blockIdx.x * SEL_TILE;
+	uint32_t c = 0;
+#pragma unroll
+	for (int it = 0; it < SEL_ITEMS; ++it) {
+		const uint32_t i = base + it * 256u + threadIdx.x;
+		bool f = false;
+		if (i < n) {
+			const float x = xyz[3ull * i + 0], z = xyz[3ull * i + 2];
+			f = in_box(keep, x, z) && !in_box(drop, x, z);
+		}
+		c += (uint32_t)__popcll(__ballot(f)); // wave-uniform
+	}
+	if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) tile_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-__global__ __launch_bounds__(256) void k_select_scatter(const float *__restrict__ xyz, uint32_t n, const uint32_t *__restrict__ flag,
-                                                         const uint32_t *__restrict__ off, uint32_t cap, float *__restrict__ out) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n || !flag[i]) return;
-	const uint32_t o = off[i];
-	if (o >= cap) return;
-	out[3ull * o + 0] = xyz[3ull * i + 0];
-	out[3ull * o + 1] = xyz[3ull * i + 1];
-	out[3ull * o + 2] = xyz[3ull * i + 2];
+// pass 2: stable compaction.  Output order = input order: item-major inside a tile, then wave, then lane.
+__global__ __launch_bounds__(256) void k_select_write(const float *__restrict__ xyz, uint32_t n, Box2 keep, Box2 drop, const uint32_t *__restrict__ tile_off,
+                                                       uint32_t cap, float *__restrict__ out) {
+	__shared__ uint32_t s_c[SEL_ITEMS * 4]; // matches of (item, wave), then their exclusive prefix in that order
+	const uint32_t base = blockIdx.x * SEL_TILE, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	uint32_t flags = 0;
+#pragma unroll
+	for (int it = 0; it < SEL_ITEMS; ++it) {
+		const uint32_t i = base + it * 256u + threadIdx.x;
+		bool f = false;
+		if (i < n) {
+			const float x = xyz[3ull * i + 0], z = xyz[3ull * i + 2];
+			f = in_box(keep, x, z) && !in_box(drop, x, z);
+		}
+		const uint64_t b = __ballot(f);
+		if (lane == 0) s_c[it * 4 + w] = (uint32_t)__popcll(b);
+		flags |= (f ? 1u : 0u) << it;
+	}
+	__syncthreads();
+	if (threadIdx.x < 64) { // 64 counters: one wave scans them
+		const uint32_t v = s_c[threadIdx.x];
+		const uint32_t inc = wave_incl_scan(v);
+		s_c[threadIdx.x] = inc - v;
+	}
+	__syncthreads();
+	if (!flags) return;
+	const uint32_t tile_base = tile_off[blockIdx.x];
+#pragma unroll
+	for (int it = 0; it < SEL_ITEMS; ++it) {
+		const bool f = (flags >> it) & 1u;
+		const uint64_t b = __ballot(f); // lanes that left hold no flag: the ballot of the remaining ones is still exact
+		if (!f) continue;
+		const uint32_t o = tile_base + s_c[it * 4 + w] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+		if (o >= cap) continue;
+		const uint32_t i = base + it * 256u + threadIdx.x;
+		out[3ull * o + 0] = xyz[3ull * i + 0];
+		out[3ull * o + 1] = xyz[3ull * i + 1];
+		out[3ull * o + 2] = xyz[3ull * i + 2];
+	}
 }
 
 } // namespace
@@ -48,14 +94,15 @@ extern "C" int32_t treee_select_xz_dev(treee_ctx *ctx, const float *d_xyz, uint6
 		TREEE_HIP(hipMemsetAsync(d_count_out, 0, 4, ctx->stream));
 		return TREEE_OK;
 	}
-	uint32_t *d_flag = nullptr, *d_off = nullptr;
-	TREEE_TRY(ctx->alloc_t(n, &d_flag));
-	TREEE_TRY(ctx->alloc_t(n, &d_off));
+	const uint32_t ntiles = div_up(n, SEL_TILE);
+	uint32_t *d_tiles = nullptr, *d_off = nullptr;
+	TREEE_TRY(ctx->alloc_t(ntiles, &d_tiles));
+	TREEE_TRY(ctx->alloc_t(ntiles, &d_off));
 	const Box2 keep = {keep_box[0], keep_box[1], keep_box[2], keep_box[3]}, drop = {drop_box[0], drop_box[1], drop_box[2], drop_box[3]};
-	hipLaunchKernelGGL(k_select_flag, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, keep, drop, d_flag);
+	hipLaunchKernelGGL(k_select_count, dim3(ntiles), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, keep, drop, d_tiles);
 	TREEE_LAUNCH_CHECK();
-	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_flag, d_off, n, d_count_out));
-	hipLaunchKernelGGL(k_select_scatter, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, d_flag, d_off,
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_tiles, d_off, ntiles, d_count_out));
+	hipLaunchKernelGGL(k_select_write, dim3(ntiles), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, keep, drop, d_off,
 	                   (uint32_t)(cap < 0xFFFFFFFFull ? cap : 0xFFFFFFFFull), d_out_xyz);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
