@@ -300,6 +300,31 @@ def test_segmented_curvature_vs_per_segment_oracle(T, oracle):
     assert np.array_equal(one.view(np.uint32), whole.view(np.uint32))
 
 
+def test_saved_project_to_per_segment_curvature(T):
+    """F2 -> A5: a project saved in the reference's `.ipc` layout is read back and every segment's `curve` comes
+    out of one call, identical to the same call on the in-memory arrays"""
+    from treee_amd import ipc, synth
+
+    pts, seg = synth.forest_cloud(80_000, plot=16.0)
+    seg = seg.astype(np.uint32)
+    save = {"segments": {}, "deleted": {"points": np.zeros((0, 3), np.float32), "classifications": np.zeros(0, np.uint32),
+                                        "info": dict(trunk_height=0.0, crown_height=0.0, ground_sep=0.0, crown_sep=0.0),
+                                        "min": np.zeros(3, np.float32), "max": np.zeros(3, np.float32), "coords": None},
+            "world_offset": np.array([500000.0, 120.0, -5.3e6]), "source_location": "+proj=utm\n+ellps=GRS80\n+zone=32"}
+    for sg in np.unique(seg):
+        p = pts[seg == sg]
+        save["segments"][int(sg) * 2654435761 % 2**32] = {  # arbitrary u32 ids like rand::random (segmenting.rs:516-519)
+            "points": p, "classifications": np.full(len(p), ipc.CROWN, np.uint32),
+            "info": dict(trunk_height=1.0, crown_height=2.0, ground_sep=0.5, crown_sep=3.0), "min": p.min(0), "max": p.max(0), "coords": None}
+    back = ipc.read_ipc(ipc.write_ipc(save))
+    cloud, segment, ids = ipc.to_cloud(back)
+    assert len(cloud) == len(pts) and len(ids) == len(np.unique(seg))
+    got = T.curvature_segments(cloud, segment, len(ids))
+    order = np.concatenate([np.nonzero(seg == sg)[0] for sg in np.unique(seg)])  # to_cloud lists segment after segment
+    want = T.curvature_segments(pts, seg, int(seg.max()) + 1)[order]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 # ---------------------------------------------------------------- A6-A7 splat
 def default_camera(T, w, h):
     cam = T.Camera3D(w / h)

@@ -109,6 +109,37 @@ def _ghost_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def test_ipc_bincode_layout_and_round_trip():
+    """`.ipc` = bincode 1.3.3 defaults of InteractiveSave (interactive/mod.rs:44-50): a hand-assembled byte vector
+    (one segment with two points, an empty `deleted`) decodes to the expected values and re-encodes identically"""
+    import struct
+
+    from treee_amd import ipc
+
+    f32, f64, u32, u64 = (lambda *v: struct.pack("<%df" % len(v), *v)), (lambda *v: struct.pack("<%dd" % len(v), *v)), (
+        lambda v: struct.pack("<I", v)), (lambda v: struct.pack("<Q", v))
+    seg = (u64(2) + f32(1.0, 2.0, 3.0, -4.5, 0.25, 8.0)  # points: Vec<Point3<f32>>: u64 length, 3 f32 each, no inner prefix
+           + u64(2) + u32(ipc.TRUNK) + u32(ipc.CROWN)    # classifications: u64 length, u32 variant index each
+           + f32(1.5, 2.5, 0.5, 3.5)                     # info: four f32 in declaration order
+           + f32(-4.5, 0.25, 3.0) + f32(1.0, 2.0, 8.0)   # min, max
+           + b"\x01" + f64(48.137, 11.575))             # coords: Some((f64, f64))
+    empty = u64(0) + u64(0) + f32(0, 0, 0, 0) + f32(0, 0, 0) + f32(0, 0, 0) + b"\x00"
+    loc = "+proj=utm\n+ellps=GRS80\n+zone=32".encode()  # DEFAULT_LOCATION, interactive/mod.rs:53
+    blob = u64(1) + u32(0xDEADBEEF) + seg + empty + f64(500000.5, 120.25, -5300000.75) + u64(len(loc)) + loc
+    save = ipc.read_ipc(blob)
+    s = save["segments"][0xDEADBEEF]
+    assert s["points"].tolist() == [[1.0, 2.0, 3.0], [-4.5, 0.25, 8.0]] and s["classifications"].tolist() == [1, 2]
+    assert s["info"] == {"trunk_height": 1.5, "crown_height": 2.5, "ground_sep": 0.5, "crown_sep": 3.5}
+    assert s["coords"] == (48.137, 11.575) and save["deleted"]["coords"] is None and len(save["deleted"]["points"]) == 0
+    assert save["world_offset"].tolist() == [500000.5, 120.25, -5300000.75] and save["source_location"].startswith("+proj=utm")
+    assert ipc.write_ipc(save) == blob
+    pts, segment, ids = ipc.to_cloud(save)
+    assert pts.shape == (2, 3) and segment.tolist() == [0, 0] and ids == [0xDEADBEEF]
+    for bad in (blob[:-1], blob + b"\0", blob.replace(u32(ipc.CROWN), u32(7), 1)):
+        with pytest.raises(ValueError):
+            ipc.read_ipc(bad)
+
+
 def test_partition_segments_is_balanced_and_deterministic():
     from treee_amd import distributed as D
     from treee_amd import synth
