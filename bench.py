@@ -244,6 +244,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": measured_traffic(m_knn),
+                "valu_busy": measured_valu_busy(m_knn),
                 "algorithmic_bytes_per_point": BYTES["knn_curve"],
                 "points_per_launch": m_knn,
                 "kernel_ms": round(knn_ms, 3),
@@ -412,6 +413,22 @@ def out_of_core_stage(dev, n, proj, tiles=67):
         res[name] = {"points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1),
                      "pcie_GBps": round(r["points"] * 20 / dt / 1e9, 1)}
     return res
+
+
+def measured_valu_busy(points):
+    """What actually bounds the kernel (it is not HBM): fraction of SIMD cycles that issue a VALU instruction, from the
+    committed SQ counters (profiles/knn_pmc.sh): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the share of ONE wave's lifetime,
+    a SIMD holds 3 waves of this kernel."""
+    try:
+        import glob
+
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v*_knn_sq_pmc.json")), key=lambda p: int(p.split("_v")[1].split("_")[0]))[-1]
+        c = json.load(open(path))
+        if points != 15_000_000:
+            return None
+        return round(3.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3)
+    except Exception:
+        return None
 
 
 def measured_traffic(points):
