@@ -148,6 +148,8 @@ struct SortedCloud {
 	float4 *d_sorted = nullptr;  // (x,y,z,bitcast(orig)) sorted
 	int device = 0;
 	int crowded = -1; // some Morton cell holds more than LONG_RUN points: -1 unknown, else 0 / 1 (long_run_flag_dev)
+	float *d_cube = nullptr;   // (corner.xyz, size) on the device when the cube was computed from the data
+	bool cube_pending = false; // corner / size above are not yet valid on the host (cube_fetch_async + cube_commit)
 	treee_ctx *owner = nullptr; // context whose pool the arrays came from
 	SortedCloud() = default;
 	SortedCloud(const SortedCloud &) = delete;
@@ -165,6 +167,12 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 #endif
 constexpr uint32_t LONG_RUN = TREEE_LONG_RUN;
 int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_sorted_keys, uint64_t n, uint32_t *d_flag);
+// The cube of a cloud built from its data stays on the device (keys are generated from there); the host copy is
+// brought over by whichever host round trip of the build comes next: enqueue with cube_fetch_async, and after that
+// synchronisation call cube_commit.  Both are no-ops when the host copy is already valid.
+int32_t cube_fetch_async(treee_ctx *ctx, SortedCloud *sc, float h_cube[4]);
+void cube_commit(SortedCloud *sc, const float h_cube[4]);
+int32_t cube_to_host(treee_ctx *ctx, SortedCloud *sc); // both, with a synchronisation of its own (paths without another one)
 
 // default context for the host-pointer API (created lazily, one per process)
 int32_t default_ctx(treee_ctx **out);

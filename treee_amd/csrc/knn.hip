@@ -1252,7 +1252,7 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 	*out = sc;
 	const uint64_t n = sc->n;
 	static const bool off = getenv("TREEE_KNN_NO_REFINE") != nullptr; // A/B and test hook
-	if (n <= LONG_RUN || off) return TREEE_OK;
+	if (n <= LONG_RUN || off) return cube_to_host(ctx, sc.get());
 	hipStream_t st = ctx->stream;
 	uint32_t flag = 0;
 	if (sc->crowded >= 0) { // the octree build already asked (its own host round trip carried the answer)
@@ -1262,8 +1262,11 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 		TREEE_TRY(ctx->alloc_t(1, &d_flag));
 		TREEE_TRY(long_run_flag_dev(ctx, sc->d_keys, n, d_flag));
 		TREEE_HIP(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+		float h_cube[4] = {0, 0, 0, 1};
+		TREEE_TRY(cube_fetch_async(ctx, sc.get(), h_cube));
 		TREEE_HIP(hipStreamSynchronize(st));
 		sc->crowded = (int)flag;
+		cube_commit(sc.get(), h_cube);
 	}
 	if (!flag) return TREEE_OK;
 	auto fine = std::make_shared<SortedCloud>();

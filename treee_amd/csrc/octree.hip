@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_oct_finish(treee_octree_node *__restric
 
 int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 	const uint64_t n = o->sc->n;
-	if (n == 0) return TREEE_OK;
+	if (n == 0) return cube_to_host(ctx, o->sc.get());
 	hipStream_t st = ctx->stream;
 	// Capacity per level: a node is split only if it holds more than leaf_cap points, so a level has at
 	// most n/(leaf_cap+1) split nodes and the next one at most 8x that many nodes (and never more than
@@ -202,12 +202,15 @@ int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 	TREEE_TRY(ctx->alloc_t(1, &d_crowded));
 	TREEE_TRY(long_run_flag_dev(ctx, o->sc->d_keys, n, d_crowded));
 	TREEE_HIP(hipMemcpyAsync(&crowded, d_crowded, 4, hipMemcpyDeviceToHost, st));
+	float h_cube[4] = {0, 0, 0, 1};
+	TREEE_TRY(cube_fetch_async(ctx, o->sc.get(), h_cube));
 	TREEE_HIP(hipMemcpyAsync(h_last, d_lvl + 2 * DEPTH, 8, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipMemcpyAsync(&lod_total, d_total, 4, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipStreamSynchronize(st));
 	o->n_nodes = (uint64_t)h_last[0] + h_last[1];
 	o->n_lod = lod_total;
 	o->sc->crowded = (int)crowded;
+	cube_commit(o->sc.get(), h_cube);
 	const uint32_t nn = (uint32_t)o->n_nodes;
 	TREEE_TRY(pool_alloc_t(ctx, n, &o->d_leaf));
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)(lod_total ? lod_total : 1), &o->d_lod));

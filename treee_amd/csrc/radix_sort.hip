@@ -48,6 +48,15 @@ __global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ x
 	          (spread3(quant10(z, cz, size)) << 2);
 }
 
+__global__ __launch_bounds__(256) void k_morton_keys_cube(const float *__restrict__ xyz, uint32_t n, const float *__restrict__ cube,
+                                                           uint32_t *__restrict__ keys) {
+	uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const float cx = cube[0], cy = cube[1], cz = cube[2], size = cube[3];
+	float x = xyz[3ull * i + 0], y = xyz[3ull * i + 1], z = xyz[3ull * i + 2];
+	keys[i] = spread3(quant10(x, cx, size)) | (spread3(quant10(y, cy, size)) << 1) | (spread3(quant10(z, cz, size)) << 2);
+}
+
 int32_t morton_keys_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3],
                         float size, uint32_t *d_keys) {
 	if (n == 0) return TREEE_OK;
@@ -90,6 +99,68 @@ __global__ __launch_bounds__(256) void k_bbox_partial(const float *__restrict__ 
 		for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
 		partial[blockIdx.x * 6 + threadIdx.x] = v;
 	}
+}
+
+// partials -> (corner.xyz, size) with the rules of bbox_dev below (largest extent; degenerate or non-finite -> 1 / 0)
+__global__ __launch_bounds__(256) void k_bbox_final(const float *__restrict__ partial, uint32_t grid, float *__restrict__ cube) {
+	__shared__ float s[4][6];
+	float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+	for (uint32_t b = threadIdx.x; b < grid; b += 256u)
+#pragma unroll
+		for (int a = 0; a < 6; ++a) v[a] = a < 3 ? fminf(v[a], partial[b * 6 + a]) : fmaxf(v[a], partial[b * 6 + a]);
+#pragma unroll
+	for (int a = 0; a < 6; ++a)
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float t = __shfl_down(v[a], o, 64);
+			v[a] = a < 3 ? fminf(v[a], t) : fmaxf(v[a], t);
+		}
+	if (lane_id() == 0)
+		for (int a = 0; a < 6; ++a) s[threadIdx.x >> 6][a] = v[a];
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		float mn[3], mx[3], size = 0.0f;
+		for (int a = 0; a < 3; ++a) {
+			mn[a] = fminf(fminf(s[0][a], s[1][a]), fminf(s[2][a], s[3][a]));
+			mx[a] = fmaxf(fmaxf(s[0][3 + a], s[1][3 + a]), fmaxf(s[2][3 + a], s[3][3 + a]));
+			const float e = mx[a] - mn[a];
+			if (e > size) size = e;
+		}
+		if (!(size > 0.0f) || !(size < INFINITY)) size = 1.0f;
+		for (int a = 0; a < 3; ++a) cube[a] = (mn[a] > -INFINITY && mn[a] < INFINITY) ? mn[a] : 0.0f;
+		cube[3] = size;
+	}
+}
+
+static int32_t bbox_to_device(treee_ctx *ctx, const float *d_xyz, uint64_t n, float *d_cube) {
+	uint32_t grid = n < 256 * 1024 ? div_up(n ? n : 1, 256) : 1024;
+	float *d_partial = nullptr;
+	TREEE_TRY(ctx->alloc_t(grid * 6, &d_partial));
+	hipLaunchKernelGGL(k_bbox_partial, dim3(grid), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, d_partial);
+	hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(256), 0, ctx->stream, d_partial, grid, d_cube);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+int32_t cube_fetch_async(treee_ctx *ctx, SortedCloud *sc, float h_cube[4]) {
+	if (sc->cube_pending) TREEE_HIP(hipMemcpyAsync(h_cube, sc->d_cube, 16, hipMemcpyDeviceToHost, ctx->stream));
+	return TREEE_OK;
+}
+
+int32_t cube_to_host(treee_ctx *ctx, SortedCloud *sc) {
+	if (!sc->cube_pending) return TREEE_OK;
+	float h[4] = {0, 0, 0, 1};
+	TREEE_TRY(cube_fetch_async(ctx, sc, h));
+	TREEE_HIP(hipStreamSynchronize(ctx->stream));
+	cube_commit(sc, h);
+	return TREEE_OK;
+}
+
+void cube_commit(SortedCloud *sc, const float h_cube[4]) {
+	if (!sc->cube_pending) return;
+	for (int a = 0; a < 3; ++a) sc->corner[a] = h_cube[a];
+	sc->size = h_cube[3];
+	sc->cube_pending = false;
 }
 
 int32_t bbox_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, float corner_out[3], float *size_out) {
@@ -554,12 +625,14 @@ int32_t gather_sorted_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_
 }
 
 void SortedCloud::release() {
-	if (d_keys || d_perm || d_sorted) (void)hipSetDevice(device);
+	if (d_keys || d_perm || d_sorted || d_cube) (void)hipSetDevice(device);
 	pool_release(owner, d_keys);
 	pool_release(owner, d_perm);
 	pool_release(owner, d_sorted);
+	pool_release(owner, d_cube);
 	d_keys = d_perm = nullptr;
 	d_sorted = nullptr;
+	d_cube = nullptr;
 }
 
 // every LONG_RUN_STEP-th position is probed: a run longer than LONG_RUN + LONG_RUN_STEP is always found, one
@@ -586,8 +659,10 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 	if (corner && size > 0.0f) {
 		for (int a = 0; a < 3; ++a) sc->corner[a] = corner[a];
 		sc->size = size;
-	} else {
-		TREEE_TRY(bbox_dev(ctx, d_xyz, n, sc->corner, &sc->size));
+	} else { // cube from the data: it stays on the device, the host copy follows with the build's next round trip
+		TREEE_TRY(pool_alloc_t(ctx, 4, &sc->d_cube));
+		TREEE_TRY(bbox_to_device(ctx, d_xyz, n, sc->d_cube));
+		sc->cube_pending = true;
 	}
 	size_t cnt = n ? n : 1;
 	TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_keys));
@@ -595,7 +670,12 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 	TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_sorted));
 	uint32_t *d_keys_raw = nullptr;
 	TREEE_TRY(ctx->alloc_t(cnt, &d_keys_raw));
-	TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
+	if (sc->cube_pending) {
+		if (n) hipLaunchKernelGGL(k_morton_keys_cube, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, sc->d_cube, d_keys_raw);
+		TREEE_LAUNCH_CHECK();
+	} else {
+		TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
+	}
 	TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, sc->d_keys, sc->d_perm));
 	TREEE_TRY(gather_sorted_dev(ctx, d_xyz, sc->d_perm, n, sc->d_sorted));
 	return TREEE_OK;
