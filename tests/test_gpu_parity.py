@@ -985,6 +985,63 @@ def test_cpp_host_mirror_program(T):
     assert "all checks passed" in r.stdout
 
 
+def _shard_worker(rank, world, port, out_dir):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import treee_amd as T
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    dev = torch.device("cuda", 0)
+    plot, n, halo = 20.0, 50_000, 3.0
+    ctx = T.default_context(dev)
+    pts, _ = synth.forest_cloud_torch(n, dev, plot=plot, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, plot))
+    bounds = D.tile_bounds(rank, world, plot)
+    cloud = D.GhostExchanger(pts, bounds, halo, rank, world, ctx=ctx).exchange(halo)
+    tree = T.KDTree.new(cloud, ctx)
+    d, _, c = tree.self_neighbors_dev(31)
+    ok = D.halo_is_sufficient(pts, d[:n, 30], bounds, halo, rank, world)
+    curve = tree.curvature_dev(31, n_own=n)
+    torch.save({"pts": pts.cpu(), "dist": d[:n].cpu(), "count": c[:n].cpu(), "ok": ok, "curve": curve.cpu(), "ghosts": cloud.shape[0] - n},
+               os.path.join(out_dir, f"shard{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path):
+    """with a sufficient (verified) halo, every own point of a shard finds exactly the neighbours it finds
+    when one GPU holds the whole cloud -- distances bit for bit; curvature within the tie tolerance"""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"shard{r}.pt")) for r in range(2)]
+    whole = torch.cat([r["pts"] for r in res]).cuda()
+    tree = T.KDTree.new(whole)
+    d, _, c = tree.self_neighbors_dev(31)
+    curve = tree.curvature_dev(31)
+    torch.cuda.synchronize()
+    o = 0
+    for r in res:
+        n = r["pts"].shape[0]
+        assert r["ok"] is True and r["ghosts"] > 1000
+        assert torch.equal(r["dist"].view(torch.int32), d[o : o + n].cpu().view(torch.int32))
+        assert torch.equal(r["count"], c[o : o + n].cpu())
+        a, b = r["curve"].numpy(), curve[o : o + n].cpu().numpy()
+        both = ~np.isnan(b)
+        assert np.array_equal(np.isnan(a), ~both) and np.max(np.abs(a[both] - b[both])) < 1e-4
+        o += n
+
+
 def test_onesweep_sort_variant_bit_exact(T):
     """the optional onesweep radix passes (decoupled look-back across workgroups, TREEE_SORT_ONESWEEP=1)
     must give the same bits as the default hist/scan/scatter passes"""
