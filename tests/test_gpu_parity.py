@@ -1007,7 +1007,17 @@ def _shard_worker(rank, world, port, out_dir):
     d, _, c = tree.self_neighbors_dev(31)
     ok = D.halo_is_sufficient(pts, d[:n, 30], bounds, halo, rank, world)
     curve = tree.curvature_dev(31, n_own=n)
-    torch.save({"pts": pts.cpu(), "dist": d[:n].cpu(), "count": c[:n].cpu(), "ok": ok, "curve": curve.cpu(), "ghosts": cloud.shape[0] - n},
+    # the shard's part of the frame, drawn without values and min-reduced over the ranks (bench.py's N > 1 step)
+    w, h = 240, 135
+    view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 45.0))
+    proj = T.Camera3D(w / h).projection()
+    packed = torch.empty((h, w), dtype=torch.int64, device=dev)
+    T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h,
+                                         T.context.ptr(packed), 0, rank * n, None, None))
+    D.reduce_packed_min_async(packed).wait()
+    torch.cuda.synchronize()
+    torch.save({"pts": pts.cpu(), "dist": d[:n].cpu(), "count": c[:n].cpu(), "ok": ok, "curve": curve.cpu(), "ghosts": cloud.shape[0] - n,
+                "packed": packed.cpu()},
                os.path.join(out_dir, f"shard{rank}.pt"))
     dist.destroy_process_group()
 
@@ -1040,6 +1050,16 @@ def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path):
         both = ~np.isnan(b)
         assert np.array_equal(np.isnan(a), ~both) and np.max(np.abs(a[both] - b[both])) < 1e-4
         o += n
+    # the reduced frame is the frame one GPU draws of the whole cloud (global index = rank * n + local index)
+    w, h = 240, 135
+    view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 45.0))
+    proj = T.Camera3D(w / h).projection()
+    packed = torch.empty((h, w), dtype=torch.int64, device="cuda")
+    ctx = T.default_context(torch.device("cuda", 0))
+    T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(whole), None, whole.shape[0], T.context.ptr(view), T.context.ptr(proj), 0.3, 0,
+                                         0xFFFFFFFF, w, h, T.context.ptr(packed), 0, 0, None, None))
+    assert torch.equal(packed.cpu(), res[0]["packed"]) and torch.equal(res[0]["packed"], res[1]["packed"])
+    assert int((packed != packed.max()).sum()) > 500
 
 
 def test_onesweep_sort_variant_bit_exact(T):
