@@ -170,15 +170,19 @@ def main():
         step(False)
     torch.cuda.synchronize()
 
-    # multi-GPU exactness of the unbounded-radius kNN: verify the halo once, outside the timing
+    # multi-GPU exactness of the unbounded-radius kNN: the halo is verified outside the timing and widened until
+    # every own query's k-th neighbour lies inside it (the verdict is collective, so all ranks loop alike)
+    halo_verified = world == 1
     if world > 1:
-        step(False)
-        tree = state["tree"]
-        d, _, _ = tree.self_neighbors_dev(K, F32_MAX, ctx, want_index=False)
-        ok = D.halo_is_sufficient(pts, d[:n, K - 1], bounds, halo, rank, world)
-        del d
-        free_state()
-        if not ok:
+        for _ in range(6):
+            step(False)
+            tree = state["tree"]
+            d, _, _ = tree.self_neighbors_dev(K, F32_MAX, ctx, want_index=False)
+            halo_verified = bool(D.halo_is_sufficient(pts, d[:n, K - 1], bounds, halo, rank, world))
+            del d
+            free_state()
+            if halo_verified:
+                break
             halo *= 2.0
             if rank == 0:
                 print(f"# halo widened to {halo} m", file=sys.stderr)
@@ -235,6 +239,7 @@ def main():
                 "k": K,
                 "framebuffer": [W, H],
                 "parallelism": f"spatial x/z tiles {D.tile_grid(world)[0]}x{D.tile_grid(world)[1]}, ghost all-gather halo {halo} m",
+                "halo_verified": halo_verified,
             },
             "roofline": {
                 "kernel": "k_knn (kNN k=31 + covariance/eigen -> curve)",

@@ -20,6 +20,20 @@
  *     with TREEE_ERR_HIP
  *   - indices on the device are u32 (<= 2^32-2 points per shard); the host structs widen to
  *     u64 like Rust's usize
+ *
+ * Streams
+ *   - a handle (treee_knn, treee_octree) is OWNED by the context that built it: its arrays come from
+ *     that context's block pool and return to it on free, where later builds on the owner's stream
+ *     reuse them without synchronising
+ *   - any _dev entry point may be given a DIFFERENT context than the handle's owner: the library then
+ *     makes that context's stream wait for the work the owner's stream holds (the build), remembers
+ *     the use with an event, and treee_*_free makes the owner's stream wait for those events before the
+ *     arrays can be reused.  Freeing a handle right after enqueueing a query on another stream is safe;
+ *     neither call blocks the host
+ *   - pointers obtained from treee_octree_dev_ptr are the caller's to order: they are valid until
+ *     treee_octree_free, and work the CALLER enqueues on them from other streams must be complete (or
+ *     ordered before the owner's stream) when the handle is freed
+ *   - a context is used by one host thread at a time; different contexts may be used concurrently
  */
 #ifndef TREEE_HIP_H
 #define TREEE_HIP_H

@@ -1010,19 +1010,24 @@ def test_segments_dealt_to_ranks_give_the_same_curvature(T):
         assert np.mean(got[~nan].view(np.uint32) == whole[~nan].view(np.uint32)) > 0.99
 
 
-def _shard_worker(rank, world, port, out_dir):
+def _shard_worker(rank, world, port, out_dir, backend="gloo"):
     import os
 
     import torch
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: both ranks share GPU 0 and the collectives are staged through the host; nccl (= RCCL): one GPU per rank
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import treee_amd as T
     from treee_amd import distributed as D
     from treee_amd import synth
 
-    dev = torch.device("cuda", 0)
     plot, n, halo = 20.0, 50_000, 3.0
     ctx = T.default_context(dev)
     pts, _ = synth.forest_cloud_torch(n, dev, plot=plot, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, plot))
@@ -1047,9 +1052,18 @@ def _shard_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path):
+def _rccl_available():
+    import torch
+
+    return torch.cuda.device_count() >= 2
+
+
+@pytest.mark.parametrize("backend", ["gloo", pytest.param("nccl", marks=pytest.mark.skipif("not _rccl_available()", reason="RCCL needs two GPUs (the gpurun box has one)"))])
+def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path, backend):
     """with a sufficient (verified) halo, every own point of a shard finds exactly the neighbours it finds
-    when one GPU holds the whole cloud -- distances bit for bit; curvature within the tie tolerance"""
+    when one GPU holds the whole cloud -- distances bit for bit; curvature within the tie tolerance.  `nccl` runs the
+    RCCL branches (all_gather_into_tensor on the ghost blocks, the asynchronous int64 MIN all-reduce of the frame) on
+    two GPUs and is skipped on a one-GPU box."""
     import socket
 
     import torch
@@ -1058,7 +1072,7 @@ def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path), backend), nprocs=2, join=True)
     res = [torch.load(os.path.join(tmp_path, f"shard{r}.pt")) for r in range(2)]
     whole = torch.cat([r["pts"] for r in res]).cuda()
     tree = T.KDTree.new(whole)
@@ -1087,23 +1101,36 @@ def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path):
     assert int((packed != packed.max()).sum()) > 500
 
 
-def test_onesweep_sort_variant_bit_exact(T):
-    """the optional onesweep radix passes (decoupled look-back across workgroups, TREEE_SORT_ONESWEEP=1)
-    must give the same bits as the default hist/scan/scatter passes"""
-    import os
-    import subprocess
-    import sys
+def test_handle_used_from_another_stream_is_ordered(T):
+    """Stream contract of include/treee_hip.h ("Streams"): a handle built on one context may be queried through
+    another one (another HIP stream) and freed right afterwards; its arrays return to the owner's pool, and the next
+    build on the owner's stream -- which reuses exactly those blocks -- must not run under the still-reading query.
+    The host-pointer build lives on the library's private stream, the query on a side stream behind a long kernel."""
+    import numpy as np
+    import torch
 
-    code = ("import numpy as np, hashlib, treee_amd as T\n"
-            "from treee_amd import synth\n"
-            "p,_=synth.forest_cloud(700_001, plot=40.0)\n"
-            "o=T.Octree(p); print(hashlib.sha256(o.array('keys').tobytes()+o.array('perm').tobytes()+o.array('leaf').tobytes()).hexdigest())\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = []
-    for flag in (False, True):
-        env = dict(os.environ, PYTHONPATH=root)
-        env.pop("TREEE_SORT_ONESWEEP", None)
-        if flag:
-            env["TREEE_SORT_ONESWEEP"] = "1"
-        out.append(subprocess.check_output([sys.executable, "-c", code], env=env, text=True).strip().splitlines()[-1])
-    assert out[0] == out[1]
+    from oracle import oracle as O
+    from treee_amd import synth
+
+    pts, _ = synth.forest_cloud(300_000, plot=30.0)
+    other, _ = synth.forest_cloud(300_000, plot=30.0, seed=99)
+    f32max = float(np.finfo(np.float32).max)
+    ref_ent, ref_cnt = O.KDTree(pts).k_nearest_batch(pts[:4096], 31, f32max, threads=4)
+    side = torch.cuda.Stream()
+    spin = torch.empty((64 << 20,), dtype=torch.float32, device="cuda")
+    q = torch.from_numpy(pts[:4096]).cuda()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        tree = T.KDTree.new(pts)  # host API: built on the default context's private stream
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                spin.mul_(1.0001)  # the query below starts late on the side stream
+            ctx = T.default_context(torch.device("cuda", 0))  # context of torch's *current* stream (the side stream)
+            dist, index, counts = tree.k_nearest_dev(q, 31, f32max, ctx)
+        tree.close()  # arrays go back to the owner's pool while the side stream may still be reading them
+        del tree
+        clobber = T.KDTree.new(other)  # same sizes: takes the very blocks just released
+        clobber.close()
+        side.synchronize()
+        assert np.array_equal(counts.cpu().numpy(), ref_cnt.astype(np.int32))
+        assert np.array_equal(dist.cpu().numpy().view(np.uint32), ref_ent["distance"].view(np.uint32))

@@ -45,10 +45,31 @@ def test_las_header_chunks_and_errors():
         Header(img[:200])
     with pytest.raises(CorruptFile):
         Header(b"LASX" + img[4:])
-    lazy = bytearray(img)
-    lazy[104] |= 0x80
-    with pytest.raises(NotImplementedError):
-        Laz(bytes(lazy))
+    # LAZ is recognised by its laszip VLR (laz.rs:77-79: user id "laszip encoded", record id 22204), not by the
+    # compression bit of the point format: the 52 spare header bytes... are not VLRs, so splice one in
+    import struct
+
+    vlr = bytearray(54 + 8)
+    vlr[2:16] = b"laszip encoded"
+    struct.pack_into("<HH", vlr, 18, 22204, 8)
+    other_vlr = bytearray(54 + 4)
+    other_vlr[2:12] = b"LASF_Projn"[:10]
+    struct.pack_into("<HH", other_vlr, 18, 34735, 4)
+    for vlrs, is_laz in (((other_vlr,), False), ((other_vlr, vlr), True)):
+        extra = b"".join(bytes(v) for v in vlrs)
+        f = bytearray(img[:427] + extra + img[427:])
+        struct.pack_into("<I", f, 96, 427 + len(extra))   # offset_to_point_data
+        struct.pack_into("<I", f, 100, len(vlrs))          # number_of_variable_length_records
+        if is_laz:
+            with pytest.raises(NotImplementedError):
+                Laz(bytes(f))
+        else:
+            assert Laz(bytes(f)).chunks[0] == (427 + len(extra), 50_000)
+    flagged = bytearray(img)
+    flagged[104] |= 0x80  # the format's compression bit alone does not make the reference take the LAZ branch
+    assert Laz(bytes(flagged)).total() == 3
+    with pytest.raises(CorruptFile):  # a truncated file: the reference's read_exact fails (laz.rs:146-170)
+        Laz(img[:-5])
 
 
 def test_camera_helpers():

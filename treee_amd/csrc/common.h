@@ -87,6 +87,9 @@ struct treee_ctx {
 	size_t cur = 0; // block index
 	size_t off = 0; // offset in blocks[cur]
 	int num_cus = 256;
+	// pinned landing area for the few scalars a build brings back (node counts, flags, the cube): an asynchronous
+	// device-to-host copy must never target a stack frame that an early error return can unwind before the copy runs
+	uint32_t *h_scalars = nullptr; // [64]
 
 	// pool of persistent blocks (the arrays owned by kNN / octree handles).  Reuse is ordered by
 	// this context's stream, so a block can be handed out again without synchronising.
@@ -109,6 +112,27 @@ struct treee_ctx {
 };
 
 namespace treee {
+
+// ---- handles used from a stream other than their owner's ----------------------------------------------
+// A handle's arrays come from its owner context's pool and go back to it on free, where the next pool_alloc hands
+// them out again WITHOUT synchronising: reuse is ordered by the owner's stream.  That only covers work the owner's
+// stream can see, but every _dev entry point accepts any context.  Stream contract (treee_hip.h, "Streams"):
+//   use_begin  -- the using stream waits for everything the owner's stream has been given so far (the build)
+//   use_end    -- an event on the using stream remembers the last foreign use
+//   retire     -- before the arrays go back to the pool the owner's stream waits for those events
+// Same stream (or the same context): all three are no-ops.
+struct HandleSync {
+	std::mutex mu;
+	std::vector<std::pair<hipStream_t, hipEvent_t>> users; // last use per foreign stream
+	HandleSync() = default;
+	HandleSync(const HandleSync &) = delete;
+	HandleSync &operator=(const HandleSync &) = delete;
+	~HandleSync();
+};
+bool ctx_is_live(treee_ctx *ctx);
+int32_t use_begin(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs);
+int32_t use_end(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs);
+void retire(treee_ctx *owner, HandleSync *hs);
 
 // ---- internal stage entry points (device pointers, enqueue on ctx->stream) ---------------
 // radix_sort.hip
@@ -151,6 +175,7 @@ struct SortedCloud {
 	float *d_cube = nullptr;   // (corner.xyz, size) on the device when the cube was computed from the data
 	bool cube_pending = false; // corner / size above are not yet valid on the host (cube_fetch_async + cube_commit)
 	treee_ctx *owner = nullptr; // context whose pool the arrays came from
+	mutable HandleSync sync;    // uses of the arrays from other streams (see HandleSync)
 	SortedCloud() = default;
 	SortedCloud(const SortedCloud &) = delete;
 	SortedCloud &operator=(const SortedCloud &) = delete;

@@ -82,6 +82,57 @@ void pool_release(treee_ctx *ctx, void *p) {
 	(void)hipFree(p);
 }
 
+bool ctx_is_live(treee_ctx *ctx) {
+	std::lock_guard<std::mutex> live(g_live_mu);
+	return ctx && g_live.count(ctx);
+}
+
+static bool foreign(treee_ctx *ctx, treee_ctx *owner) { return ctx && owner && ctx != owner && ctx->stream != owner->stream; }
+
+int32_t use_begin(treee_ctx *ctx, treee_ctx *owner, HandleSync *) {
+	if (!foreign(ctx, owner) || !ctx_is_live(owner)) return TREEE_OK; // (a destroyed owner synchronised its stream: the build is done)
+	hipEvent_t ev = nullptr;
+	TREEE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+	hipError_t e = hipEventRecord(ev, owner->stream);
+	if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+	(void)hipEventDestroy(ev); // the wait holds its own reference to the recorded state
+	if (e != hipSuccess) return set_err(TREEE_ERR_HIP, "cross-stream wait for a handle's owner: %s", hipGetErrorString(e));
+	return TREEE_OK;
+}
+
+int32_t use_end(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs) {
+	if (!foreign(ctx, owner)) return TREEE_OK;
+	std::lock_guard<std::mutex> lk(hs->mu);
+	hipEvent_t ev = nullptr;
+	for (auto &u : hs->users)
+		if (u.first == ctx->stream) ev = u.second;
+	if (!ev) {
+		TREEE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		hs->users.push_back({ctx->stream, ev});
+	}
+	TREEE_HIP(hipEventRecord(ev, ctx->stream));
+	return TREEE_OK;
+}
+
+void retire(treee_ctx *owner, HandleSync *hs) {
+	std::lock_guard<std::mutex> lk(hs->mu);
+	const bool live = ctx_is_live(owner);
+	for (auto &u : hs->users) {
+		// a live owner's stream waits (no host stall); otherwise the block becomes an ordinary allocation and the
+		// host waits here
+		if (!live || hipStreamWaitEvent(owner->stream, u.second, 0) != hipSuccess) (void)hipEventSynchronize(u.second);
+		(void)hipEventDestroy(u.second);
+	}
+	hs->users.clear();
+}
+
+HandleSync::~HandleSync() {
+	for (auto &u : users) {
+		(void)hipEventSynchronize(u.second);
+		(void)hipEventDestroy(u.second);
+	}
+}
+
 static std::mutex g_default_mu;
 std::recursive_mutex &default_ctx_mutex() {
 	static std::recursive_mutex m;
@@ -186,6 +237,12 @@ int32_t treee_ctx_create(int32_t device, void *hip_stream, treee_ctx **out) {
 	c->own_stream = false;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+	e = hipHostMalloc((void **)&c->h_scalars, 64 * sizeof(uint32_t), hipHostMallocDefault);
+	if (e != hipSuccess) {
+		delete c;
+		return set_err(TREEE_ERR_NOMEM, "pinned scalar block: %s", hipGetErrorString(e));
+	}
+	memset(c->h_scalars, 0, 64 * sizeof(uint32_t));
 	{
 		std::lock_guard<std::mutex> lk(g_live_mu);
 		g_live.insert(c);
@@ -205,6 +262,7 @@ int32_t treee_ctx_destroy(treee_ctx *ctx) {
 	for (auto &b : ctx->pool_idle) (void)hipFree(b.p);
 	for (auto &b : ctx->blocks) (void)hipFree(b.p);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+	if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
 	delete ctx;
 	return TREEE_OK;
 }

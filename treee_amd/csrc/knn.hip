@@ -34,6 +34,7 @@ struct treee_knn {
 	uint32_t n_order = 0;        // its length (8 * the longest XCD segment)
 	int device = 0;
 	treee_ctx *owner = nullptr;
+	mutable HandleSync sync; // uses of d_bvh / d_order from other streams (the sorted cloud carries its own)
 };
 
 namespace {
@@ -1065,8 +1066,22 @@ uint32_t max_bits(float max_dist_sq) {
 	return b;
 }
 
+int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_t nq, uint32_t k, float max_dist_sq,
+                      float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit);
+
+// every query path comes through here: a context other than the handle's owner is ordered behind the build and its
+// use is remembered for treee_knn_free (HandleSync in common.h)
 int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_t nq, uint32_t k, float max_dist_sq,
                    float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit = ~0ull) {
+	TREEE_TRY(use_begin(ctx, t->owner, &t->sync));
+	if (t->sc->owner != t->owner) TREEE_TRY(use_begin(ctx, t->sc->owner, &t->sc->sync));
+	const int32_t rc = launch_knn_on(ctx, t, d_q, nq, k, max_dist_sq, d_dist, d_index, d_counts, d_curve, q_limit);
+	const int32_t e1 = use_end(ctx, t->owner, &t->sync), e2 = use_end(ctx, t->sc->owner, &t->sc->sync);
+	return rc != TREEE_OK ? rc : (e1 != TREEE_OK ? e1 : e2);
+}
+
+int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_t nq, uint32_t k, float max_dist_sq,
+                      float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit) {
 	if (k == 0) return set_err(TREEE_ERR_INVALID, "k == 0 (the reference panics at best_set.rs:74)");
 	if (nq == 0) return TREEE_OK;
 	if (nq >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "nq too large");
@@ -1116,6 +1131,7 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		a.q_start = d_qs;
 	}
 	static const bool force_heap = getenv("TREEE_KNN_FORCE_HEAP") != nullptr; // A/B and test hook
+	static const unsigned pad_lds = getenv("TREEE_KNN_PAD_LDS") ? (unsigned)atoi(getenv("TREEE_KNN_PAD_LDS")) : 0u; // A/B hook: unused dynamic LDS lowers the occupancy
 	static const bool no64 = getenv("TREEE_KNN_NO_K64") != nullptr; // A/B and test hook
 	if (k > (uint32_t)SK && k <= 64u && !force_heap && !no64 && !t->segmented) {
 		if (a.wave_order && !d_q) nwaves = t->n_order;
@@ -1133,7 +1149,7 @@ int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_
 		else if (a.stats)
 			hipLaunchKernelGGL((k_knn_sorted32<true, false>), dim3(nwaves), dim3(64), 0, ctx->stream, a);
 		else
-			hipLaunchKernelGGL((k_knn_sorted32<false, false>), dim3(nwaves), dim3(64), 0, ctx->stream, a);
+			hipLaunchKernelGGL((k_knn_sorted32<false, false>), dim3(nwaves), dim3(64), pad_lds, ctx->stream, a);
 	} else {
 		if (t->segmented) return set_err(TREEE_ERR_UNSUPPORTED, "segmented handle: k=%u > 32 is not supported", k);
 		a.wave_order = nullptr;
@@ -1261,10 +1277,12 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 		uint32_t *d_flag = nullptr;
 		TREEE_TRY(ctx->alloc_t(1, &d_flag));
 		TREEE_TRY(long_run_flag_dev(ctx, sc->d_keys, n, d_flag));
-		TREEE_HIP(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, st));
-		float h_cube[4] = {0, 0, 0, 1};
+		uint32_t *h = ctx->h_scalars; // pinned, owned by the context: an early return cannot leave a copy aimed at a dead frame
+		float *h_cube = (float *)(h + 4);
+		TREEE_HIP(hipMemcpyAsync(h, d_flag, 4, hipMemcpyDeviceToHost, st));
 		TREEE_TRY(cube_fetch_async(ctx, sc.get(), h_cube));
 		TREEE_HIP(hipStreamSynchronize(st));
+		flag = h[0];
 		sc->crowded = (int)flag;
 		cube_commit(sc.get(), h_cube);
 	}
@@ -1506,7 +1524,7 @@ int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, tree
 	if (!d_xyz) return set_err(TREEE_ERR_INVALID, "treee_knn_build_dev: xyz is null");
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
-	treee_knn *t = new treee_knn;
+	treee_knn *t = new treee_knn; // (after reset(): nothing to leak if that fails)
 	t->device = ctx->device;
 	t->n_points = n;
 	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, nullptr, 0.0f, t->sc.get());
@@ -1534,9 +1552,11 @@ int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_k
 	t->device = ctx->device;
 	t->sc = sc; // one Morton sort, two consumers
 	t->n_points = sc->n;
-	TREEE_TRY(ctx->reset());
-	int32_t rc = refine_dense_cells(ctx, sc, &t->sc); // (a private, finer-sorted copy if a Morton cell is crowded)
+	int32_t rc = ctx->reset();
+	if (rc == TREEE_OK) rc = use_begin(ctx, sc->owner, &sc->sync); // the octree may have been built on another stream
+	if (rc == TREEE_OK) rc = refine_dense_cells(ctx, sc, &t->sc); // (a private, finer-sorted copy if a Morton cell is crowded)
 	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
+	if (rc == TREEE_OK) rc = use_end(ctx, sc->owner, &sc->sync);
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);
 		return rc;
@@ -1564,6 +1584,11 @@ int32_t treee_knn_build(const float *xyz, uint64_t n, treee_knn **out) {
 int32_t treee_knn_free(treee_knn *t) {
 	if (!t) return TREEE_OK;
 	(void)hipSetDevice(t->device);
+	// uses from other streams: the owners' streams wait for them before the arrays can be handed out again.  (The
+	// cloud's own events are retired when its last reference goes; retiring them here too keeps a still-shared
+	// cloud's owner ordered behind this handle's users.)
+	if (t->sc) retire(t->sc->owner, &t->sc->sync);
+	retire(t->owner, &t->sync);
 	t->sc.reset();
 	pool_release(t->owner, t->d_bvh);
 	pool_release(t->owner, t->d_order);

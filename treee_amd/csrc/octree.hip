@@ -21,6 +21,8 @@ struct treee_octree {
 	int device = 0;
 	treee_ctx *owner = nullptr;
 };
+// (the octree's own arrays are only ever touched by its owner's stream and by the caller through
+// treee_octree_dev_ptr, whose ordering is the caller's; the shared sorted cloud carries a HandleSync)
 
 namespace {
 
@@ -197,19 +199,21 @@ int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 	hipLaunchKernelGGL(k_oct_lod_count, dim3(div_up(nodes_cap, 256)), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * DEPTH, (uint32_t)nodes_cap, o->lod_cap, d_lcnt);
 	TREEE_LAUNCH_CHECK();
 	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_lcnt, d_loff, nodes_cap, d_total));
-	uint32_t h_last[2] = {0, 0}, lod_total = 0, crowded = 0;
+	// the round trip lands in the context's pinned scalars: [0] crowded, [1..2] last level, [3] LOD total, [4..7] cube
+	uint32_t *h = ctx->h_scalars;
+	float *h_cube = (float *)(h + 4);
 	uint32_t *d_crowded = nullptr; // asked here so that a kNN structure sharing this cloud needs no round trip of its own
 	TREEE_TRY(ctx->alloc_t(1, &d_crowded));
 	TREEE_TRY(long_run_flag_dev(ctx, o->sc->d_keys, n, d_crowded));
-	TREEE_HIP(hipMemcpyAsync(&crowded, d_crowded, 4, hipMemcpyDeviceToHost, st));
-	float h_cube[4] = {0, 0, 0, 1};
+	TREEE_HIP(hipMemcpyAsync(h + 0, d_crowded, 4, hipMemcpyDeviceToHost, st));
 	TREEE_TRY(cube_fetch_async(ctx, o->sc.get(), h_cube));
-	TREEE_HIP(hipMemcpyAsync(h_last, d_lvl + 2 * DEPTH, 8, hipMemcpyDeviceToHost, st));
-	TREEE_HIP(hipMemcpyAsync(&lod_total, d_total, 4, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipMemcpyAsync(h + 1, d_lvl + 2 * DEPTH, 8, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipMemcpyAsync(h + 3, d_total, 4, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipStreamSynchronize(st));
-	o->n_nodes = (uint64_t)h_last[0] + h_last[1];
+	const uint32_t lod_total = h[3];
+	o->n_nodes = (uint64_t)h[1] + h[2];
 	o->n_lod = lod_total;
-	o->sc->crowded = (int)crowded;
+	o->sc->crowded = (int)h[0];
 	cube_commit(o->sc.get(), h_cube);
 	const uint32_t nn = (uint32_t)o->n_nodes;
 	TREEE_TRY(pool_alloc_t(ctx, n, &o->d_leaf));

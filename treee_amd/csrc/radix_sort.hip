@@ -149,7 +149,7 @@ int32_t cube_fetch_async(treee_ctx *ctx, SortedCloud *sc, float h_cube[4]) {
 
 int32_t cube_to_host(treee_ctx *ctx, SortedCloud *sc) {
 	if (!sc->cube_pending) return TREEE_OK;
-	float h[4] = {0, 0, 0, 1};
+	float *h = (float *)(ctx->h_scalars + 4); // pinned (see treee_ctx::h_scalars)
 	TREEE_TRY(cube_fetch_async(ctx, sc, h));
 	TREEE_HIP(hipStreamSynchronize(ctx->stream));
 	cube_commit(sc, h);
@@ -335,145 +335,6 @@ __global__ __launch_bounds__(256) void k_iota_copy(const uint32_t *__restrict__ 
 	vals_out[i] = vals_in ? vals_in[i] : i;
 }
 
-// ---- onesweep variant: one global histogram for all digits, one kernel per digit ---------------
-// Each 4096-key tile ranks its keys exactly like rs_scatter, but instead of reading a pre-scanned
-// table[digit][tile] it chains the per-digit offsets through decoupled look-back: a tile publishes
-// its 256 digit counts, walks back over its predecessors' published values until it meets an
-// inclusive prefix, then publishes its own inclusive prefix.  Drops the per-pass key re-read
-// (rs_hist) and the row scan: 16 B/key per pass + 4 B/key once.
-//
-// Inter-workgroup protocol (MI355X: per-XCD L2s are not coherent, cdna_hip_programming.md G16 R2):
-// every published word is ONE naturally aligned 8-byte granule {state:2 | value:32} written by a
-// relaxed agent-scope atomic store (write-through) and polled by relaxed agent-scope atomic loads;
-// the data is its own flag, so no fence is needed.  Tile ids are handed out by an atomic counter in
-// start order, so a predecessor has always started (placement- and dispatch-order independent).
-// Spins are bounded: on timeout the tile raises an error word and carries on (garbage, no hang).
-constexpr unsigned long long OS_AGG = 1ull << 62, OS_INC = 2ull << 62, OS_VAL = 0xFFFFFFFFull;
-constexpr uint32_t OS_SPIN_LIMIT = 1u << 22;
-
-__global__ __launch_bounds__(256) void os_hist(const uint32_t *__restrict__ keys, uint32_t n, int passes, uint32_t *__restrict__ ghist /*[4][256]*/) {
-	__shared__ uint32_t h[4][256];
-	const int tid = threadIdx.x;
-#pragma unroll
-	for (int p = 0; p < 4; ++p) h[p][tid] = 0;
-	__syncthreads();
-	for (uint32_t i = blockIdx.x * 256u + tid; i < n; i += gridDim.x * 256u) {
-		const uint32_t k = keys[i];
-		for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
-	}
-	__syncthreads();
-	for (int p = 0; p < passes; ++p)
-		if (h[p][tid]) atomicAdd(&ghist[p * 256 + tid], h[p][tid]);
-}
-
-__global__ __launch_bounds__(RS_BLOCK) void os_pass(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
-                                                    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, int shift,
-                                                    const uint32_t *__restrict__ ghist /*[256] of this pass*/, unsigned long long *status /*[ntiles][256]*/,
-                                                    uint32_t *tile_counter, uint32_t *error_word) {
-	__shared__ uint32_t s_keys[RS_TILE];
-	__shared__ uint32_t s_vals[RS_TILE];
-	__shared__ uint32_t s_whist[4][256];
-	__shared__ uint32_t s_goff[256];
-	__shared__ uint32_t s_part[4];
-	__shared__ uint32_t s_tile;
-	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
-#pragma unroll
-	for (int i = 0; i < 4; ++i) s_whist[i][tid] = 0;
-	__syncthreads();
-	const uint32_t tile = s_tile;
-	const uint32_t tile_base = tile * RS_TILE;
-	const uint32_t base = tile_base + w * (64 * RS_ITEMS) + lane;
-	uint32_t key[RS_ITEMS], val[RS_ITEMS], rank[RS_ITEMS];
-#pragma unroll
-	for (int i = 0; i < RS_ITEMS; ++i) {
-		const uint32_t idx = base + i * 64;
-		const bool ok = idx < n;
-		key[i] = ok ? keys_in[idx] : 0xFFFFFFFFu; // padding sorts last inside the tile
-		val[i] = ok ? (vals_in ? vals_in[idx] : idx) : 0u;
-	}
-	const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-	for (int i = 0; i < RS_ITEMS; ++i) {
-		const uint32_t d = (key[i] >> shift) & 255u;
-		uint64_t peers = ~0ull;
-#pragma unroll
-		for (int b = 0; b < 8; ++b) {
-			const bool bit = (d >> b) & 1u;
-			const uint64_t m = __ballot(bit);
-			peers &= bit ? m : ~m;
-		}
-		const uint32_t cnt = __popcll(peers);
-		const int leader = 63 - __clzll((long long)peers);
-		uint32_t old = 0;
-		if (lane == leader) old = atomicAdd(&s_whist[w][d], cnt);
-		old = __shfl(old, leader, 64);
-		rank[i] = old + __popcll(peers & lt_mask);
-	}
-	__syncthreads();
-	{
-		const uint32_t c0 = s_whist[0][tid], c1 = s_whist[1][tid], c2 = s_whist[2][tid], c3 = s_whist[3][tid];
-		// padding keys (digit 255 of the last tile) must not enter the chained counts
-		const uint32_t tile_count = (n - tile_base) < (uint32_t)RS_TILE ? (n - tile_base) : (uint32_t)RS_TILE;
-		const uint32_t pad = tid == 255 ? (uint32_t)RS_TILE - tile_count : 0u;
-		const uint32_t mine = c0 + c1 + c2 + c3 - pad;
-		unsigned long long *row = status + (size_t)tile * 256 + tid;
-		// publish the aggregate (tile 0: it is the inclusive prefix already)
-		__hip_atomic_store(row, (tile == 0 ? OS_INC : OS_AGG) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		uint32_t excl = 0;
-		if (tile > 0) { // decoupled look-back over the predecessors, one digit per thread
-			uint32_t t = tile;
-			bool done = false;
-			while (!done && t > 0) {
-				--t;
-				const unsigned long long *prow = status + (size_t)t * 256 + tid;
-				unsigned long long v = 0;
-				uint32_t spins = 0;
-				for (;;) {
-					v = __hip_atomic_load(prow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (v >> 62) break;
-					if (++spins > OS_SPIN_LIMIT) {
-						atomicExch(error_word, 1u);
-						v = OS_INC; // give up: wrong result, but no hang
-						break;
-					}
-					__builtin_amdgcn_s_sleep(1);
-				}
-				excl += (uint32_t)(v & OS_VAL);
-				done = (v >> 62) == 2ull;
-			}
-			__hip_atomic_store(row, OS_INC | (unsigned long long)(excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		const uint32_t dstart = block_excl_scan_256(c0 + c1 + c2 + c3, s_part, nullptr);
-		const uint32_t gstart = block_excl_scan_256(ghist[tid], s_part, nullptr);
-		s_whist[0][tid] = dstart;
-		s_whist[1][tid] = dstart + c0;
-		s_whist[2][tid] = dstart + c0 + c1;
-		s_whist[3][tid] = dstart + c0 + c1 + c2;
-		s_goff[tid] = gstart + excl - dstart;
-	}
-	__syncthreads();
-#pragma unroll
-	for (int i = 0; i < RS_ITEMS; ++i) {
-		const uint32_t d = (key[i] >> shift) & 255u;
-		const uint32_t pos = s_whist[w][d] + rank[i];
-		s_keys[pos] = key[i];
-		s_vals[pos] = val[i];
-	}
-	__syncthreads();
-	const uint32_t tile_count = (n - tile_base) < (uint32_t)RS_TILE ? (n - tile_base) : (uint32_t)RS_TILE;
-#pragma unroll
-	for (int i = 0; i < RS_ITEMS; ++i) {
-		const uint32_t p = i * RS_BLOCK + tid;
-		if (p < tile_count) {
-			const uint32_t k = s_keys[p];
-			const uint32_t o = s_goff[(k >> shift) & 255u] + p;
-			keys_out[o] = k;
-			vals_out[o] = s_vals[p];
-		}
-	}
-}
-
 int32_t sort_pairs_dev(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in,
                        uint64_t n64, int bits, uint32_t *d_keys_out, uint32_t *d_vals_out) {
 	if (n64 == 0) return TREEE_OK;
@@ -489,35 +350,9 @@ int32_t sort_pairs_dev(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t
 	uint32_t *d_ktmp = nullptr, *d_vtmp = nullptr;
 	TREEE_TRY(ctx->alloc_t(n, &d_ktmp));
 	TREEE_TRY(ctx->alloc_t(n, &d_vtmp));
-	// Measured on MI355X, 15 M pairs: onesweep 4 x 93.9 us + 29.9 us = 405 us vs 4 x (72.9 + 25.5 + 6.0) us
-	// = 418 us for hist / scan / scatter -- the look-back latency cancels the saved key re-read, so the
-	// simpler three-kernel pass (no inter-workgroup protocol at all) stays the default.
-	static const bool onesweep = getenv("TREEE_SORT_ONESWEEP") != nullptr;
-	if (onesweep && passes <= 4) {
-		// onesweep: global histograms of all digits once, then one chained kernel per digit
-		uint32_t *d_ghist = nullptr, *d_ctrl = nullptr; // ctrl: [0..3] tile counters, [4] error word
-		unsigned long long *d_status = nullptr;
-		TREEE_TRY(ctx->alloc_t(4 * 256, &d_ghist));
-		TREEE_TRY(ctx->alloc_t(8, &d_ctrl));
-		TREEE_TRY(ctx->alloc_t((size_t)passes * ntiles * 256, &d_status));
-		TREEE_HIP(hipMemsetAsync(d_ghist, 0, 4 * 256 * 4, ctx->stream));
-		TREEE_HIP(hipMemsetAsync(d_ctrl, 0, 32, ctx->stream));
-		TREEE_HIP(hipMemsetAsync(d_status, 0, (size_t)passes * ntiles * 256 * 8, ctx->stream));
-		const uint32_t hgrid = n < 256u * 1024u ? div_up(n, 256) : 1024u;
-		hipLaunchKernelGGL(os_hist, dim3(hgrid), dim3(256), 0, ctx->stream, d_keys_in, n, passes, d_ghist);
-		const uint32_t *kin = d_keys_in, *vin = d_vals_in;
-		for (int p = 0; p < passes; ++p) {
-			const bool to_out = ((passes - 1 - p) % 2) == 0;
-			uint32_t *kout = to_out ? d_keys_out : d_ktmp;
-			uint32_t *vout = to_out ? d_vals_out : d_vtmp;
-			hipLaunchKernelGGL(os_pass, dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, kin, vin, kout, vout, n, 8 * p, d_ghist + p * 256,
-			                   d_status + (size_t)p * ntiles * 256, d_ctrl + p, d_ctrl + 4);
-			TREEE_LAUNCH_CHECK();
-			kin = kout;
-			vin = vout;
-		}
-		return TREEE_OK;
-	}
+	// (A onesweep variant -- one global histogram, decoupled look-back per digit pass -- was measured in round 1:
+	// 405 vs 418 us per 15 M-pair sort, the look-back latency cancelling the saved key re-read.  It was dropped:
+	// the three-kernel pass has no inter-workgroup protocol and so no timeout path to get wrong.)
 	uint32_t *d_table = nullptr, *d_totals = nullptr;
 	TREEE_TRY(ctx->alloc_t((size_t)256 * ntiles, &d_table));
 	TREEE_TRY(ctx->alloc_t(256, &d_totals));
@@ -626,6 +461,7 @@ int32_t gather_sorted_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_
 
 void SortedCloud::release() {
 	if (d_keys || d_perm || d_sorted || d_cube) (void)hipSetDevice(device);
+	retire(owner, &sync); // the owner's stream first waits for uses from other streams (HandleSync)
 	pool_release(owner, d_keys);
 	pool_release(owner, d_perm);
 	pool_release(owner, d_sorted);

@@ -82,9 +82,12 @@ class Laz:
         self.point_length = h.point_data_record_length
         self.scale, self.offset = h.scale, h.offset
         self.center = (h.min + h.max) * 0.5 if center is None else np.asarray(center, dtype=np.float64)  # na::center
-        if h.point_data_record_format & 0x80:
+        if self._has_laszip_vlr():
             raise NotImplementedError("LAZ-compressed point data (crate `laz` 0.9.2) is outside this path")
         total = h.number_of_point_records
+        need = h.offset_to_point_data + total * self.point_length
+        if len(self.data) < need:  # the reference's read_exact fails on a short file (laz.rs:146-170)
+            raise CorruptFile(f"file holds {len(self.data)} bytes, header promises {need}")
         self.chunks = []  # laz.rs:96-107
         start = h.offset_to_point_data
         for _ in range(total // DEFAULT_CHUNK_SIZE):
@@ -95,6 +98,21 @@ class Laz:
         self.min = (h.min - self.center).astype(np.float32)
         self.max = (h.max - self.center).astype(np.float32)
         self.world_offset = self.center
+
+    def _has_laszip_vlr(self):
+        """laz.rs:77-79: the file is LAZ iff one of its variable length records is the laszip record
+        (`laz` 0.9.2 `read_vlrs_and_get_laszip_vlr`: user id "laszip encoded", record id 22204); the scan starts
+        at header_size and walks number_of_variable_length_records 54-byte VLR headers."""
+        h, pos = self.header, self.header.header_size
+        for _ in range(h.number_of_variable_length_records):
+            if pos + 54 > len(self.data):
+                return False
+            user_id = self.data[pos + 2 : pos + 18].split(b"\0", 1)[0]
+            record_id, length = struct.unpack_from("<HH", self.data, pos + 18)
+            if user_id == b"laszip encoded" and record_id == 22204:
+                return True
+            pos += 54 + length
+        return False
 
     def total(self):
         return len(self.chunks)

@@ -85,8 +85,12 @@ class TileStream:
                     tree.close()
                 else:
                     self.value[:n].fill_(0)
+                if index_base + n >= 0xFFFFFFFF:
+                    # the packed frame carries 32-bit global point ids and 0xFFFFFFFF is its "no point" sentinel
+                    raise OverflowError(f"tile {i}: global point id {index_base + n - 1} does not fit the packed frame's 32-bit id "
+                                        "(split the stream into runs of < 2^32 - 1 points)")
                 _lib.check(lib.treee_splat_dev(self.ctx.handle, ptr(xyz), ptr(self.value), n, ptr(view), ptr(proj), env.scale, env.min, env.max,
-                                               self.w, self.h, ptr(self.packed), 1, index_base & 0xFFFFFFFF, None, None))
+                                               self.w, self.h, ptr(self.packed), 1, index_base, None, None))
                 roots.append({"corner": oc.corner.tolist(), "size": oc.size, "points": n, "nodes": int(oc.n_nodes), "lod": int(oc.n_lod)})
                 if on_tile is not None:
                     on_tile(i, tile, oc, xyz)
