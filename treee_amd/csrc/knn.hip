@@ -816,12 +816,18 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 		// ---- scan the listed buckets; the next bucket's load is in flight during each scan -------
 		for (uint32_t g = 0; g < list_m; g += 64) {
 			const uint32_t gcount = (list_m - g) < 64u ? (list_m - g) : 64u;
-			const uint32_t my_leaf = (uint32_t)lane < gcount ? s_list[g + lane] : 0u;
 			// boxes of this group of listed buckets go to LDS (8 VGPRs less to carry through the scans)
 			if ((uint32_t)lane < gcount) {
+				const uint32_t my_leaf = s_list[g + lane];
 				s_gbox[lane][0] = a.bvh[2ull * (a.P + my_leaf) + 0];
 				s_gbox[lane][1] = a.bvh[2ull * (a.P + my_leaf) + 1];
 			}
+			// the id of listed bucket j is re-read from the list in LDS (one broadcast read) wherever it is needed: kept
+			// in a VGPR across the scans it was spilled, and every bucket then began with two scratch round trips --
+			// one before its record could be used, one before the next prefetch could be issued
+			auto listed = [&](uint32_t jj) __attribute__((always_inline)) -> uint32_t {
+				return (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[g + jj]);
+			};
 			__syncthreads();
 			// next listed bucket (index >= from) that some lane still needs, judged with the current
 			// threshold (it only ever shrinks, so a stale decision is merely conservative)
@@ -837,7 +843,7 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 			// the record this lane would stage for listed bucket j (clamped address: padding lanes of the
 			// last bucket read a valid record and are replaced by NaN after the wait)
 			auto bucket_ptr = [&](uint32_t jj) __attribute__((always_inline)) -> const float4 * {
-				const uint32_t i = (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, jj) * BUCKET + lane;
+				const uint32_t i = listed(jj) * BUCKET + lane;
 				return a.pts + (i < a.n ? i : a.n - 1u);
 			};
 			PH(5);
@@ -855,7 +861,7 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 			};
 			if (j < gcount) issue_prefetch(j);
 			while (j < gcount) {
-				const uint32_t leaf = (uint32_t)__builtin_amdgcn_readlane((int)my_leaf, j);
+				const uint32_t leaf = listed(j);
 				const uint64_t need_cur = need;
 				const bool inr = leaf * BUCKET + lane < a.n;
 				const float4 cand = make_float4(inr ? pf.x : nanv, inr ? pf.y : nanv, inr ? pf.z : nanv, 0.0f); // this lane's record of bucket `leaf`
