@@ -147,6 +147,32 @@ int32_t treee_curvature_segments(const float *xyz_aos, const uint32_t *segment, 
 /* map_to_u32 (treee/src/calculations.rs:455-457) over a device array */
 int32_t treee_map_to_u32_dev(treee_ctx *ctx, const float *d_in, uint64_t n, uint32_t *d_out);
 
+/* ---- F4: the Calculations phase around the kNN consumer, all segments in one call ------ */
+/* SegmentData::new for every segment of a segmented cloud (treee/src/calculations.rs:133-175, run per segment by
+ * Calculations::new :97-118): seg_min / seg_max [n_segments][3]; SegmentInformation::new (:210-276) ->
+ * seg_info [n_segments][4] = {trunk_height, crown_height, ground_sep, crown_sep}, from the areas of one convex hull
+ * per 0.1 m slice (get_size_areas :429-452, Tree::new / insert / statistics treee/src/segmenting.rs:258-269,346-396,
+ * 320-323); classification [n] = 0 Ground / 1 Trunk / 2 Crown (:149-163; optional).  Points are inserted into a
+ * slice's hull in their order in the input arrays, as the reference inserts them in the order of the segment's
+ * Vec.  A segment without points gets min = max = 0 (:135-136).
+ * expansion / height [n] (optional, need classification): SegmentInformation::update(calc_curve = false)
+ * (:278-327) with min / max = the segment's min.y / max.y (treee/src/interactive/mod.rs:224-231).
+ * Bit-exact against the CPU restatement (hull vertices, areas, every output): only + - * / sqrt, no FMA.
+ * A segment taller than 65 534 slices (6.5 km) -> TREEE_ERR_UNSUPPORTED; segment id >= n_segments -> TREEE_ERR_INVALID. */
+int32_t treee_segments_calculate(const float *xyz_aos, const uint32_t *segment, uint64_t n, uint32_t n_segments,
+                                 float *seg_min_out, float *seg_max_out, float *seg_info_out,
+                                 uint32_t *classification_out, float *expansion_out, float *height_out);
+int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz_aos, const uint32_t *d_segment, uint64_t n,
+                                     uint32_t n_segments, float *d_seg_min, float *d_seg_max, float *d_seg_info,
+                                     uint32_t *d_classification, float *d_expansion, float *d_height);
+/* DisplayData::new (treee/src/interactive/mod.rs:1002-1039) for every segment at once: the four per-point `value`
+ * arrays the splat colours by -- classification u32::MAX/8 * {1, 3, 6}, map_to_u32(curve), map_to_u32(expansion /
+ * max expansion of the point's segment), map_to_u32(height).  Any input/output pair may be NULL. */
+int32_t treee_display_values_dev(treee_ctx *ctx, const uint32_t *d_segment, uint64_t n, uint32_t n_segments,
+                                 const uint32_t *d_classification, const float *d_curve, const float *d_expansion,
+                                 const float *d_height, uint32_t *d_classification_value, uint32_t *d_curve_value,
+                                 uint32_t *d_expansion_value, uint32_t *d_height_value);
+
 /* ---- A0: Morton sort + octree + LOD (build-defined; no reference counterpart) -------- */
 /* corner/size: the cube (render/src/camera_3d.rs:20 parametrisation); size <= 0 -> the cube is
  * computed from the data (min corner, max extent).  leaf_cap / lod_cap 0 -> 256. */

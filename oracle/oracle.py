@@ -89,6 +89,13 @@ def lib():
         L.orc_sort_keys.argtypes = [vp, u64, vp, vp]
         L.orc_octree_build.restype = u64
         L.orc_octree_build.argtypes = [vp, u64, u32, u32, vp, u64, vp, vp, u64, vp]
+        L.orc_hull_insert_all.restype = u64
+        L.orc_hull_insert_all.argtypes = [vp, u64, vp, u64, vp]
+        L.orc_size_areas.restype = u64
+        L.orc_size_areas.argtypes = [vp, u64, vp, i32, f32, f32, vp, u64]
+        L.orc_segment_data.argtypes = [vp, u64, vp, vp, vp, vp]
+        L.orc_segment_update.argtypes = [vp, vp, u64, f32, f32, vp, vp, vp]
+        L.orc_display_values.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -272,3 +279,49 @@ def octree_build(sorted_keys, leaf_cap=256, lod_cap=256):
     lod = np.zeros(lod_total.value, np.uint32)
     lib().orc_octree_build(_p(sorted_keys), n, leaf_cap, lod_cap, _p(nodes), nn, _p(leaf), _p(lod), len(lod), C.byref(lod_total))
     return nodes, leaf, lod
+
+
+# ---- Calculations phase (calc_oracle.cpp) ------------------------------------------------------------
+def hull_insert_all(xz):
+    """Tree::new(xz[0]) then Tree::insert for the rest, in order -> (hull vertices (m,2), area)."""
+    xz = _f32(xz, 2)
+    out = np.zeros((len(xz) + 2, 2), np.float32)
+    area = np.zeros(1, np.float32)
+    m = lib().orc_hull_insert_all(_p(xz), len(xz), _p(out), len(out), _p(area))
+    return out[: int(m)], float(area[0])
+
+
+def size_areas(points, min_y, height, cls=None, want_cls=2):
+    points = _f32(points, 3)
+    c = None if cls is None else np.ascontiguousarray(cls, dtype=np.uint8)
+    m = lib().orc_size_areas(_p(points), len(points), _p(c), want_cls, min_y, height, None, 0)
+    out = np.zeros(int(m), np.float32)
+    lib().orc_size_areas(_p(points), len(points), _p(c), want_cls, min_y, height, _p(out), len(out))
+    return out
+
+
+def segment_data(points):
+    """SegmentData::new for one segment -> (min[3], max[3], info[4], classification u8[n])."""
+    points = _f32(points, 3)
+    mn, mx, info = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(4, np.float32)
+    cls = np.zeros(len(points), np.uint8)
+    lib().orc_segment_data(_p(points), len(points), _p(mn), _p(mx), _p(info), _p(cls))
+    return mn, mx, info, cls
+
+
+def segment_update(points, cls, min_y, max_y, info):
+    points = _f32(points, 3)
+    cls = np.ascontiguousarray(cls, dtype=np.uint8)
+    info = _f32(info).reshape(4)
+    exp, hgt = np.zeros(len(points), np.float32), np.zeros(len(points), np.float32)
+    lib().orc_segment_update(_p(points), _p(cls), len(points), min_y, max_y, _p(info), _p(exp), _p(hgt))
+    return exp, hgt
+
+
+def display_values(cls, curve, expansion, height):
+    cls = np.ascontiguousarray(cls, dtype=np.uint8)
+    curve, expansion, height = _f32(curve), _f32(expansion), _f32(height)
+    n = len(cls)
+    out = [np.zeros(n, np.uint32) for _ in range(4)]
+    lib().orc_display_values(_p(cls), _p(curve), _p(expansion), _p(height), n, *[_p(o) for o in out])
+    return out

@@ -70,6 +70,25 @@ void orc_curvature(const float *xyz, uint64_t n, uint64_t k, float max_distance,
 /* calculations.rs:455-457 */
 uint32_t orc_map_to_u32(float v);
 
+/* ---- Calculations phase around the kNN consumer (calc_oracle.cpp) -------- */
+/* Tree::new + Tree::insert over xz[n][2] in order (treee/src/segmenting.rs:258-269,346-396); writes the hull
+ * vertices (at most cap) and Tree::statistics().area (segmenting.rs:320-323,526-545); returns the vertex count */
+uint64_t orc_hull_insert_all(const float *xz, uint64_t n, float *hull_out, uint64_t cap, float *area_out);
+/* get_size_areas (treee/src/calculations.rs:429-452); cls == NULL: every point, else only points with
+ * cls[i] == want_cls.  Returns the slice count, writes at most cap areas. */
+uint64_t orc_size_areas(const float *xyz, uint64_t n, const uint8_t *cls, int32_t want_cls, float min, float height,
+                        float *areas_out, uint64_t cap);
+/* SegmentData::new (calculations.rs:133-175) for ONE segment's points: min/max, SegmentInformation::new
+ * (:210-276) -> info = {trunk_height, crown_height, ground_sep, crown_sep}, classification 0/1/2 = Ground/Trunk/Crown */
+void orc_segment_data(const float *xyz, uint64_t n, float min_out[3], float max_out[3], float info_out[4], uint8_t *class_out);
+/* SegmentInformation::update (calculations.rs:278-327) without the curve branch: expansion[n], height[n];
+ * min / max = the segment's min.y / max.y (interactive/mod.rs:224-231) */
+void orc_segment_update(const float *xyz, const uint8_t *cls, uint64_t n, float min, float max, const float info[4],
+                        float *expansion_out, float *height_out);
+/* DisplayData::new (treee/src/interactive/mod.rs:1002-1039) for one segment: the four per-point `value` arrays */
+void orc_display_values(const uint8_t *cls, const float *curve, const float *expansion, const float *height, uint64_t n,
+                        uint32_t *cls_val, uint32_t *curve_val, uint32_t *exp_val, uint32_t *height_val);
+
 /* ---- ingest (treee/src/laz.rs, treee/src/loading.rs) --------------------- */
 /* Chunk::next_point (laz.rs:202-213) over n records of `stride` bytes */
 void orc_decode_las_records(const uint8_t *rec, uint64_t n, uint32_t stride, const double scale[3],

@@ -1134,3 +1134,109 @@ def test_handle_used_from_another_stream_is_ordered(T):
         side.synchronize()
         assert np.array_equal(counts.cpu().numpy(), ref_cnt.astype(np.int32))
         assert np.array_equal(dist.cpu().numpy().view(np.uint32), ref_ent["distance"].view(np.uint32))
+
+
+# ---- F4: the Calculations phase around the kNN consumer (calculations.hip) -----------------------------------------
+def _check_segments_against_oracle(T, O, pts, seg, S, properties=True, device=False):
+    import torch
+
+    if device:
+        r = T.segments_calculate(torch.from_numpy(pts).cuda(), torch.from_numpy(seg.astype(np.int32)).cuda(), S, properties=properties)
+        torch.cuda.synchronize()
+        got = {k: (getattr(r, k).cpu().numpy() if getattr(r, k) is not None else None) for k in ("min", "max", "info", "classification", "expansion", "height")}
+    else:
+        r = T.segments_calculate(pts, seg, S, properties=properties)
+        got = {k: getattr(r, k) for k in ("min", "max", "info", "classification", "expansion", "height")}
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)  # noqa: E731
+    for s in range(S):
+        sel = seg == s
+        q = pts[sel]
+        mn, mx, info, cls = O.segment_data(q)
+        assert np.array_equal(bits(got["min"][s]), bits(mn)) and np.array_equal(bits(got["max"][s]), bits(mx)), f"segment {s}: min/max"
+        assert np.array_equal(bits(got["info"][s]), bits(info)), f"segment {s}: info {got['info'][s]} vs {info}"
+        assert np.array_equal(got["classification"][sel].astype(np.uint8), cls), f"segment {s}: classification"
+        if properties:
+            e, h = O.segment_update(q, cls, mn[1], mx[1], info)
+            assert np.array_equal(bits(got["expansion"][sel]), bits(e)), f"segment {s}: expansion"
+            assert np.array_equal(bits(got["height"][sel]), bits(h)), f"segment {s}: height"
+    return got
+
+
+def test_segments_calculate_bit_exact_vs_oracle(T, oracle):
+    """SegmentData::new + SegmentInformation::new / update for every segment of a forest patch (ground + 65 trees + an
+    empty segment), host and device entry points, against the per-segment CPU restatement: min / max, the four
+    heights, classification, expansion and height -- all bit for bit (the slice hulls are built in the reference's
+    insertion order with the reference's arithmetic)."""
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(300_000, plot=30.0)
+    S = int(seg.max()) + 2  # the last segment has no points (calculations.rs:135-136)
+    got = _check_segments_against_oracle(T, oracle, pts, seg, S)
+    assert (got["info"][1:-1, 0] > 1.0).mean() > 0.9 and (got["info"][1:-1, 1] > 1.0).mean() > 0.9  # trees have a trunk and a crown
+    assert np.array_equal(got["info"][-1], np.zeros(4, np.float32)) and set(np.unique(got["classification"])) == {0, 1, 2}
+    _check_segments_against_oracle(T, oracle, pts, seg, S, device=True)
+    _check_segments_against_oracle(T, oracle, pts, seg, S, properties=False)
+
+
+def test_segments_calculate_follows_the_input_order(T, oracle):
+    """the hull of a slice is built by inserting its points in the order of the segment's Vec (segmenting.rs:346-396 is
+    order dependent in the last bits): a shuffled cloud must match the oracle run on the shuffled order"""
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(120_000, plot=20.0)
+    perm = np.random.default_rng(11).permutation(len(pts))
+    _check_segments_against_oracle(T, oracle, pts[perm], seg[perm], int(seg.max()) + 1)
+
+
+def test_segments_calculate_edge_cases(T, oracle):
+    """hulls that outgrow the LDS copy (points on a circle: every point becomes a vertex), slices long enough for the
+    workgroup-per-slice kernel, duplicates (zero-length edges: NaN normals, as in the reference), collinear points,
+    single-point and empty segments, a lone slice"""
+    rng = np.random.default_rng(5)
+    ang = rng.uniform(0, 2 * np.pi, 1500)
+    circle = np.stack([np.cos(ang) * 5, 1.0 + rng.uniform(0, 0.05, len(ang)), np.sin(ang) * 5], 1)  # 1500 hull vertices, one wave
+    ang = rng.uniform(0, 2 * np.pi, 5000)
+    big_circle = np.stack([np.cos(ang) * 7, 1.0 + rng.uniform(0, 0.05, len(ang)), np.sin(ang) * 7], 1)  # workgroup kernel, past its LDS copy too
+    flat = rng.normal(0, 3, (40_000, 3))
+    flat[:, 1] = rng.uniform(0, 0.25, len(flat))  # three slices of ~13 000 points: workgroup kernel
+    blob = rng.normal(0, 1, (3000, 3))
+    blob[:, 1] = np.abs(blob[:, 1]) * 3
+    line = np.stack([np.linspace(0, 4, 300), np.full(300, 0.5), np.linspace(0, 8, 300)], 1)
+    parts = [circle, big_circle, flat, blob, line, np.array([[1.0, 2.0, 3.0]]), np.repeat(np.array([[0.5, 0.5, 0.5]]), 100, 0)]
+    pts = np.concatenate(parts).astype(np.float32)
+    seg = np.concatenate([np.full(len(p), i if i < 5 else i + 1) for i, p in enumerate(parts)]).astype(np.uint32)  # segment 5 stays empty
+    _check_segments_against_oracle(T, oracle, pts, seg, 8)
+    with pytest.raises(T.TreeeError):
+        T.segments_calculate(pts, seg, 4)  # ids >= n_segments
+    tall = np.array([[0, 0, 0], [0, 7000.0, 0]], np.float32)
+    with pytest.raises(T.TreeeError):
+        T.segments_calculate(tall, np.zeros(2, np.uint32), 1)  # more than 65 534 slices
+
+
+def test_display_values_vs_oracle(T, oracle):
+    """DisplayData::new (interactive/mod.rs:1002-1039) for all segments at once: the per-point values the splat colours by"""
+    import torch
+
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(60_000, plot=14.0)
+    S = int(seg.max()) + 1
+    d_pts, d_seg = torch.from_numpy(pts).cuda(), torch.from_numpy(seg.astype(np.int32)).cuda()
+    r = T.segments_calculate(d_pts, d_seg, S)
+    curve = T.curvature_segments(d_pts, d_seg, S)
+    vals = T.display_values_dev(d_seg, S, r.classification, curve, r.expansion, r.height)
+    torch.cuda.synchronize()
+    cls, cv, ex, hg = (t.cpu().numpy() for t in (r.classification, curve, r.expansion, r.height))
+    got = {k: v.cpu().numpy().view(np.uint32) for k, v in vals.items()}
+    for s in range(S):
+        sel = seg == s
+        ref = oracle.display_values(cls[sel].astype(np.uint8), cv[sel], ex[sel], hg[sel])
+        for name, want in zip(("classification", "curve", "expansion", "height"), ref):
+            assert np.array_equal(got[name][sel], want), f"segment {s}: {name}"
+    # the values feed the splat as its per-point property (render/src/point_cloud.rs:183-193)
+    w, h = 160, 90
+    view = T.view_from_transform(T.translation(0.0, 8.0, 40.0))
+    depth, ids = T.PointCloud(d_pts).render(T.PointCloudProperty(vals["classification"]), view, T.Camera3D(w / h).projection(),
+                                            T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1), w, h)
+    seen = set(np.unique(ids.cpu().numpy().view(np.uint32))) - {0}
+    assert seen <= {0xFFFFFFFF // 8, 0xFFFFFFFF // 8 * 3, 0xFFFFFFFF // 8 * 6} and len(seen) >= 2

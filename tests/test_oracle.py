@@ -246,3 +246,62 @@ def test_golden_vectors_reproduce(oracle, golden_dir):
     h = oracle.las_header_parse(img)
     dec = oracle.decode_las_records(img[h.offset_to_point_data:], 4, 20, list(h.scale), list(h.offset), list(h.center))
     assert np.array_equal(dec, l["decoded"])
+
+
+# ---- Calculations phase (oracle/calc_oracle.cpp) --------------------------------------------------------------------
+def test_hull_insert_hand_traced(oracle):
+    """Tree::new + Tree::insert (segmenting.rs:258-269,346-396), traced by hand from the cited lines: the seed triangle is
+    (p, p + (0.1, 0), p + (0, 0.1)); a point outside exactly one run of edges replaces the vertices strictly between the
+    run's ends; a point inside changes nothing."""
+    h, a = oracle.hull_insert_all(np.array([[0, 0]], np.float32))
+    assert np.array_equal(h, np.array([[0, 0], [0.1, 0], [0, 0.1]], np.float32)) and a == np.float32(0.1) * np.float32(0.1) / 2
+    h, a = oracle.hull_insert_all(np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5]], np.float32))
+    # (1,0): outside the hypotenuse only -> inserted between (0.1,0) and (0,0.1); (1,1): between (1,0) and (0,0.1);
+    # (0,1): replaces (0,0.1)'s neighbourhood run; the seed's collinear vertices (0.1,0) and (0,0.1) stay (strict > 0)
+    assert np.array_equal(h, np.array([[0, 0], [0.1, 0], [1, 0], [1, 1], [0, 1], [0, 0.1]], np.float32)) and a == 1.0
+    h2, a2 = oracle.hull_insert_all(np.array([[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5], [0.25, 0.75], [1, 0.5]], np.float32))
+    assert np.array_equal(h2, h) and a2 == a  # interior and on-edge points are no-ops
+    # duplicates of the seed: zero-length edges never appear (the seed triangle has none), the hull is unchanged
+    h3, a3 = oracle.hull_insert_all(np.zeros((5, 2), np.float32))
+    assert len(h3) == 3 and a3 == np.float32(0.1) * np.float32(0.1) / 2
+
+
+def test_hull_matches_scipy_convex_hull_area(oracle):
+    """order-independent property: away from degeneracies the incremental hull is THE convex hull (of the points plus the
+    seed triangle's two helper vertices)"""
+    from scipy.spatial import ConvexHull
+
+    rng = np.random.default_rng(2)
+    for n in (10, 200, 5000):
+        xz = rng.normal(0, 2, (n, 2)).astype(np.float32)
+        h, a = oracle.hull_insert_all(xz)
+        ref = ConvexHull(np.concatenate([xz, xz[:1] + np.array([[0.1, 0], [0, 0.1]], np.float32)]).astype(np.float64))
+        assert abs(a - ref.volume) < 1e-3 * ref.volume and len(h) == len(ref.vertices)
+
+
+def test_segment_information_hand_case(oracle):
+    """SegmentInformation::new (calculations.rs:210-276) on a synthetic 'tree': a thin trunk from y = 0 to 5 under a
+    wide crown from 5 to 9 -> the first slice wider than a 2 m disc starts the crown; nothing near the ground is wider
+    than 1.5 x the thinnest slice of the first 10 m, so there is no ground"""
+    rng = np.random.default_rng(3)
+    trunk = np.stack([rng.uniform(-0.1, 0.1, 4000), rng.uniform(0, 5, 4000), rng.uniform(-0.1, 0.1, 4000)], 1)
+    crown = np.stack([rng.uniform(-2, 2, 40000), rng.uniform(5, 9, 40000), rng.uniform(-2, 2, 40000)], 1)
+    pts = np.concatenate([trunk, crown]).astype(np.float32)
+    mn, mx, info, cls = oracle.segment_data(pts)
+    trunk_height, crown_height, ground_sep, crown_sep = info
+    assert ground_sep == mn[1] and abs(crown_sep - 5.0) < 0.11 and abs(trunk_height - 5.0) < 0.11 and abs(crown_height - 4.0) < 0.11
+    # (SegmentData::new recomputes the separators as max.y - crown_height - trunk_height (calculations.rs:149-150): the rounding can
+    # put the very lowest point below `ground_sep`)
+    assert (cls[:4000] == 1).mean() > 0.97 and (cls[4000:] == 2).mean() > 0.97 and (cls == 0).sum() <= 2
+    e, h = oracle.segment_update(pts, cls, mn[1], mx[1], info)
+    assert h.min() == 0.0 and h.max() == 1.0 and np.nanmax(e) == 1.0
+    assert e[:4000][cls[:4000] == 1].max() == 0.0  # trunk slices hold no crown points: area 0 -> diameter 0
+    areas = oracle.size_areas(pts, mn[1], mx[1] - mn[1])
+    assert len(areas) == int(np.float32(mx[1] - mn[1]) / np.float32(0.1)) + 1 and areas[:45].max() < 0.1 and areas[55:85].min() > 10
+
+
+def test_display_values_constants(oracle):
+    out = oracle.display_values(np.array([0, 1, 2], np.uint8), np.array([0.0, 0.5, 2.0], np.float32), np.array([1.0, 2.0, 4.0], np.float32),
+                           np.array([-1.0, np.nan, 1.0], np.float32))
+    assert out[0].tolist() == [0xFFFFFFFF // 8, 0xFFFFFFFF // 8 * 3, 0xFFFFFFFF // 8 * 6]
+    assert out[1].tolist() == [0, 1 << 31, 0xFFFFFFFF] and out[2].tolist() == [1 << 30, 1 << 31, 0xFFFFFFFF] and out[3].tolist() == [0, 0, 0xFFFFFFFF]

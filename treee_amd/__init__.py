@@ -7,7 +7,14 @@ The HIP library is mandatory: importing a mirror class without it raises ImportE
 from ._lib import LIB_PATH, SYMBOLS, TreeeError, lib  # noqa: F401
 from .context import ENTRY_DTYPE, F32_MAX, INVALID_INDEX, NODE_DTYPE, Context, default_context  # noqa: F401
 from .knn import KDTree, NeighborsTree  # noqa: F401
-from .calculations import curvature, curvature_segments, map_to_u32_dev  # noqa: F401
+from .calculations import (  # noqa: F401
+    SegmentsData,
+    curvature,
+    curvature_segments,
+    display_values_dev,
+    map_to_u32_dev,
+    segments_calculate,
+)
 from .octree import Octree  # noqa: F401
 from .render import (  # noqa: F401
     Camera3D,

@@ -1,0 +1,789 @@
+// calculations.hip -- the Calculations phase around the kNN consumer, for every segment
+// of a segmented cloud in one call:
+//   SegmentData::new                  treee/src/calculations.rs:133-175   per-segment min / max, classification
+//   SegmentInformation::new           treee/src/calculations.rs:210-276   trunk / crown heights from slice areas
+//   get_size_areas                    treee/src/calculations.rs:429-452   0.1 m slices, one convex hull each
+//   Tree::new / insert / statistics   treee/src/segmenting.rs:258-269,346-396,320-323 and centroid :526-545
+//   SegmentInformation::update        treee/src/calculations.rs:278-327   expansion, height (curve: knn.hip)
+//   DisplayData::new                  treee/src/interactive/mod.rs:1002-1039  the four per-point `value` arrays
+//
+// The reference runs one rayon task per segment (calculations.rs:97) and inside it inserts the points of a slice into
+// that slice's hull one after the other.  Here the unit of parallelism is the (segment, slice) pair -- ~200 slices
+// for each of thousands of trees -- and inside a pair a whole wave works on 64 points at a time: every lane tests its
+// point against the current hull, the FIRST point (in slice order) that changes the hull is applied, the later lanes
+// test again.  A point that lies inside the hull at its turn leaves no trace, so this is exactly the sequential
+// insertion order of the reference, and the arithmetic (edge normal = normalize((dir.y, -dir.x)), dot, strict `> 0`)
+// is evaluated in the same order with correctly rounded sqrt / divide and no FMA: hull vertices and areas are
+// bit-identical to the CPU restatement (oracle/calc_oracle.cpp).
+//
+// Order of the points inside a slice = their order in the input arrays (the order of the reference's
+// `segments: HashMap<u32, Vec<Point3<f32>>>` vectors): two stable radix sorts (slice, then segment) keep it.
+#include "common.h"
+
+using namespace treee;
+
+namespace {
+
+constexpr float SLICE_WIDTH = 0.1f; // calculations.rs:16
+constexpr uint32_t SLICE_BITS = 16;  // slice index inside a segment: up to 65 535 slices = 6.5 km of height
+
+__device__ __forceinline__ uint32_t as_usize_u32(float v) { // Rust `as usize` (saturating, NaN -> 0), clamped to u32
+	if (!(v > 0.0f)) return 0u;
+	if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+	return (uint32_t)v;
+}
+
+// order-preserving u32 image of a float (-inf .. +inf; NaNs are never encoded)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+	const uint32_t b = __float_as_uint(f);
+	return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
+// f32::total_cmp as a signed integer order
+__device__ __forceinline__ int32_t f2total(float f) {
+	int32_t x = (int32_t)__float_as_uint(f);
+	x ^= (int32_t)((uint32_t)(x >> 31) >> 1);
+	return x;
+}
+__device__ __forceinline__ float total2f(int32_t x) {
+	x ^= (int32_t)((uint32_t)(x >> 31) >> 1);
+	return __uint_as_float((uint32_t)x);
+}
+
+__global__ __launch_bounds__(256) void k_check_segments(const uint32_t *__restrict__ seg, uint32_t n, uint32_t nseg, uint32_t *__restrict__ err) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n && seg[i] >= nseg) atomicOr(err, 1u);
+}
+
+// start[s] = first position of segment s in the segment-sorted order, start[nseg] = n
+__global__ __launch_bounds__(256) void k_starts(const uint32_t *__restrict__ sorted_seg, uint32_t n, uint32_t nseg, uint32_t *__restrict__ start) {
+	const uint32_t sg = blockIdx.x * 256u + threadIdx.x;
+	if (sg > nseg) return;
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint32_t mid = lo + ((hi - lo) >> 1);
+		if (sorted_seg[mid] < sg)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	start[sg] = lo;
+}
+
+// ---- SegmentData::new, min / max (calculations.rs:135-147) --------------------------------------------------
+// f32::min / f32::max drop a NaN operand, so the result is the extreme of the non-NaN values: an order-independent
+// reduction.  Points come in segment order, so a wave usually holds one segment: it reduces with shuffles and lane 0
+// issues the six atomics; a wave that straddles a boundary lets every lane issue its own.
+__global__ __launch_bounds__(256) void k_init_aabb(uint32_t *__restrict__ aabb, uint32_t nseg) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < nseg * 6u) aabb[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u; // [s][0..2] = min (ordered image), [3..5] = max
+}
+__global__ __launch_bounds__(256) void k_seg_aabb(const float *__restrict__ xyz, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ sorted_seg,
+                                                   uint32_t n, uint32_t *__restrict__ aabb) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	const bool live = i < n;
+	const uint32_t sg = live ? sorted_seg[i] : 0xFFFFFFFFu;
+	uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+	if (live) {
+		const uint32_t o = perm[i];
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			const float v = xyz[3ull * o + d];
+			if (v == v) lo[d] = hi[d] = f2ord(v);
+		}
+	}
+	const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sg);
+	if (__all(sg == first)) {
+#pragma unroll
+		for (int d = 0; d < 3; ++d)
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o, 64));
+				hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o, 64));
+			}
+		if ((threadIdx.x & 63u) == 0 && first != 0xFFFFFFFFu) {
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				if (lo[d] != 0xFFFFFFFFu) atomicMin(&aabb[first * 6u + d], lo[d]);
+				if (hi[d] != 0u) atomicMax(&aabb[first * 6u + 3u + d], hi[d]);
+			}
+		}
+	} else if (live) {
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			if (lo[d] != 0xFFFFFFFFu) atomicMin(&aabb[sg * 6u + d], lo[d]);
+			if (hi[d] != 0u) atomicMax(&aabb[sg * 6u + 3u + d], hi[d]);
+		}
+	}
+}
+// decode; an empty segment is (0, 0, 0) (calculations.rs:135-136), a segment whose every value along an axis is NaN keeps NaN
+// (min(NaN, NaN)); slice count of the segment (calculations.rs:217, 435)
+__global__ __launch_bounds__(256) void k_seg_finish_aabb(const uint32_t *__restrict__ aabb, const uint32_t *__restrict__ start, uint32_t nseg,
+                                                          float *__restrict__ seg_min, float *__restrict__ seg_max, uint32_t *__restrict__ n_slices,
+                                                          uint32_t *__restrict__ err) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= nseg) return;
+	const bool empty = start[s + 1] == start[s];
+	float mn[3], mx[3];
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		const uint32_t a = aabb[s * 6u + d], b = aabb[s * 6u + 3u + d];
+		mn[d] = empty ? 0.0f : (a == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : ord2f(a));
+		mx[d] = empty ? 0.0f : (b == 0u ? __uint_as_float(0x7FC00000u) : ord2f(b));
+		seg_min[s * 3u + d] = mn[d];
+		seg_max[s * 3u + d] = mx[d];
+	}
+	const float height = mx[1] - mn[1];
+	const uint32_t raw = as_usize_u32(height / SLICE_WIDTH);
+	if (raw >= (1u << SLICE_BITS) - 1u) atomicOr(err, 2u);
+	n_slices[s] = (raw >= (1u << SLICE_BITS) - 1u ? (1u << SLICE_BITS) - 2u : raw) + 1u;
+}
+
+// slice of every point, original order: ((pos.y - min) / SLICE_WIDTH) as usize (calculations.rs:442)
+__global__ __launch_bounds__(256) void k_slice_index(const float *__restrict__ xyz, const uint32_t *__restrict__ seg, uint32_t n,
+                                                      const float *__restrict__ seg_min, const uint32_t *__restrict__ n_slices, uint32_t *__restrict__ slice) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t sg = seg[i];
+	const uint32_t idx = as_usize_u32((xyz[3ull * i + 1] - seg_min[sg * 3u + 1]) / SLICE_WIDTH);
+	const uint32_t ns = n_slices[sg];
+	slice[i] = idx < ns ? idx : ns - 1u; // (min <= y <= max: always inside; the clamp only guards a capped segment)
+}
+__global__ __launch_bounds__(256) void k_gather(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) dst[i] = src[idx[i]];
+}
+// task = run of equal (segment, slice) in the final order; flag its first element
+__global__ __launch_bounds__(256) void k_task_flags(const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice, uint32_t n,
+                                                     uint32_t *__restrict__ flag) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	flag[i] = (i == 0 || sorted_seg[i] != sorted_seg[i - 1] || sorted_slice[i] != sorted_slice[i - 1]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_task_starts(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ task_of, uint32_t n,
+                                                      uint32_t *__restrict__ task_start) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	if (flag[i]) task_start[task_of[i]] = i;
+}
+
+// ---- Tree::new / insert / statistics for one (segment, slice) per wave -----------------------------------------
+constexpr uint32_t HULL_LDS = 512; // hull vertices kept in LDS per wave; a larger hull moves to the task's slot in HBM
+
+struct P2 {
+	float x, y;
+};
+
+// segmenting.rs:347-353: the outward unit normal of the edge a -> b, normalize((dir.y, -dir.x)) = v / sqrt(x*x + y*y).
+// It depends on the edge only, so it is computed when the hull changes and kept beside the vertex (the square root and
+// the two divisions are ~100 instructions; the per-point test that is left is 2 sub, 2 mul, 1 add, 1 compare).
+__device__ __forceinline__ P2 edge_normal(P2 a, P2 b) {
+	const float dx = b.x - a.x, dy = b.y - a.y;
+	const float ox = dy, oy = -dx;
+	const float norm = sqrtf(ox * ox + oy * oy);
+	return P2{ox / norm, oy / norm};
+}
+__device__ __forceinline__ bool edge_outside(P2 a, P2 nrm, P2 p) {
+	const float fx = p.x - a.x, fy = p.y - a.y;
+	const float dist = nrm.x * fx + nrm.y * fy;
+	return dist > 0.0f;
+}
+
+// Slices of BIG_TASK points or more (the ground of a plot holds hundreds of thousands per slice) get a workgroup of 16
+// waves instead of one wave: 1024 points are tested per round, everything else is the same algorithm.
+constexpr uint32_t BIG_TASK = 2048, BIG_THREADS = 1024, BIG_LDS = 2048;
+__global__ __launch_bounds__(256) void k_big_tasks(const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n, uint32_t *__restrict__ big_list,
+                                                    uint32_t *__restrict__ big_count) {
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	if (t >= n_tasks) return;
+	const uint32_t count = (t + 1u < n_tasks ? task_start[t + 1u] : n) - task_start[t];
+	if (count >= BIG_TASK) big_list[atomicAdd(big_count, 1u)] = t; // (any order: the tasks are independent)
+}
+
+// one wave per task.  `cls` (optional): only points with cls[orig] == want take part (calculations.rs:299-301).
+__global__ __launch_bounds__(256) void k_slice_hulls(const float *__restrict__ xyz, const uint32_t *__restrict__ order /* final order -> original index */,
+                                                      const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
+                                                      const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
+                                                      const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
+                                                      P2 *__restrict__ spill /* [2 * n + 4 * n_tasks] */, float *__restrict__ areas) {
+	__shared__ P2 s_hull[4][2 * HULL_LDS]; // vertices, then the outward normal of the edge that starts at each vertex
+	const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t t = blockIdx.x * 4u + w;
+	if (t >= n_tasks) return; // (whole waves leave: no block-wide barrier below)
+	const uint32_t begin = task_start[t], end = t + 1u < n_tasks ? task_start[t + 1u] : n;
+	const uint32_t count = end - begin;
+	if (count >= BIG_TASK) return; // a whole workgroup takes it (k_slice_hulls_big)
+	P2 *H = s_hull[w], *N = s_hull[w] + HULL_LDS;  // generic pointers: LDS first, HBM after an overflow
+	P2 *const big = spill + 2ull * begin + 4ull * t; // room for count + 2 vertices and as many normals
+	uint32_t cap = HULL_LDS, m = 0;                // m = hull size, 0 = no Tree yet
+	auto sync = [&]() __attribute__((always_inline)) { // the wave's own writes before its next reads
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+	};
+	auto normals = [&]() __attribute__((always_inline)) { // all of them again: a splice renumbers the edges
+		for (uint32_t c = 0; c < m; c += 64u) {
+			const uint32_t j = c + lane;
+			if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+		}
+		sync();
+	};
+
+	for (uint32_t base = 0; base < count; base += 64u) {
+		const uint32_t i = base + lane;
+		bool pending = i < count;
+		P2 p = {0.0f, 0.0f};
+		if (pending) {
+			const uint32_t o = order[begin + i];
+			p.x = xyz[3ull * o + 0];
+			p.y = xyz[3ull * o + 2];
+			if (cls) pending = cls[o] == want;
+		}
+		for (;;) {
+			uint64_t pm = __ballot(pending);
+			if (!pm) break;
+			if (m == 0) { // Tree::new (segmenting.rs:258-269) from the first point of the slice
+				const int f = __builtin_ctzll(pm);
+				const float px = __shfl(p.x, f, 64), py = __shfl(p.y, f, 64);
+				if (lane == 0) {
+					H[0] = P2{px, py};
+					H[1] = P2{px + 0.1f, py};
+					H[2] = P2{px, py + 0.1f};
+				}
+				m = 3;
+				pending = pending && (int)lane > f;
+				sync();
+				normals();
+				continue;
+			}
+			// Tree::insert, scan part (segmenting.rs:356-370): every pending lane against the current hull
+			bool has_s = false, has_e = false;
+			uint32_t st = 0, en = 0;
+			{
+				bool last = edge_outside(H[m - 1u], N[m - 1u], p);
+				for (uint32_t j = 0; j < m; ++j) {
+					const bool out = edge_outside(H[j], N[j], p);
+					if (!last && out) {
+						st = j;
+						has_s = true;
+					} else if (last && !out) {
+						en = j;
+						has_e = true;
+					}
+					last = out;
+				}
+			}
+			const bool modifies = pending && has_s && has_e;
+			const uint64_t mm = __ballot(modifies);
+			if (!mm) break; // nobody of this batch changes the hull any more
+			const int f = __builtin_ctzll(mm); // the first one in slice order: everything before it was a no-op
+			const uint32_t s0 = (uint32_t)__shfl((int)st, f, 64), e0 = (uint32_t)__shfl((int)en, f, 64);
+			const float px = __shfl(p.x, f, 64), py = __shfl(p.y, f, 64);
+			// splice (segmenting.rs:374-380), cooperative.  Lanes move in lockstep: every lane reads its element before any
+			// lane writes, and the chunks run in the direction that never overwrites an unread source.
+			uint32_t new_m;
+			if (e0 < s0) { // H' = H[e0 ..= s0] + [point]
+				const uint32_t keep = s0 - e0 + 1u;
+				if (e0 > 0u)
+					for (uint32_t c = 0; c < keep; c += 64u) {
+						const uint32_t k = c + lane;
+						P2 v = {0.0f, 0.0f};
+						if (k < keep) v = H[e0 + k];
+						__builtin_amdgcn_wave_barrier();
+						if (k < keep) H[k] = v;
+						sync();
+					}
+				if (lane == 0) H[keep] = P2{px, py};
+				new_m = keep + 1u;
+			} else { // H' = H[0 ..= s0] + [point] + H[e0 .. m)
+				const uint32_t tail = m - e0, dst = s0 + 2u;
+				new_m = dst + tail;
+				if (new_m > cap) { // the hull outgrows its LDS copy: continue in the task's HBM slot
+					for (uint32_t c = 0; c < m; c += 64u)
+						if (c + lane < m) big[c + lane] = H[c + lane];
+					H = big;
+					N = big + (count + 2u);
+					cap = 0xFFFFFFFFu;
+					sync();
+				}
+				if (dst < e0) { // shrink: shift the tail left, ascending
+					for (uint32_t c = 0; c < tail; c += 64u) {
+						const uint32_t k = c + lane;
+						P2 v = {0.0f, 0.0f};
+						if (k < tail) v = H[e0 + k];
+						__builtin_amdgcn_wave_barrier();
+						if (k < tail) H[dst + k] = v;
+						sync();
+					}
+				} else if (dst > e0) { // grow by one: shift the tail right, descending
+					for (uint32_t c = (tail + 63u) / 64u; c-- > 0u;) {
+						const uint32_t k = c * 64u + lane;
+						P2 v = {0.0f, 0.0f};
+						if (k < tail) v = H[e0 + k];
+						__builtin_amdgcn_wave_barrier();
+						if (k < tail) H[dst + k] = v;
+						sync();
+					}
+				}
+				if (lane == 0) H[s0 + 1u] = P2{px, py};
+			}
+			m = new_m;
+			pending = pending && (int)lane > f;
+			sync();
+			normals();
+		}
+	}
+	// Tree::statistics().area = centroid(points).1 (segmenting.rs:526-545): triangle fan around points[0], summed in order
+	if (lane == 0 && m >= 3u) {
+		float area = 0.0f;
+		const P2 a = H[0];
+		for (uint32_t i = 1; i + 1u < m; ++i) {
+			const P2 b = H[i], c = H[i + 1u];
+			const float bx = b.x - a.x, by = b.y - a.y, cx = c.x - a.x, cy = c.y - a.y;
+			area += bx * cy - by * cx;
+		}
+		areas[slice_off[sorted_seg[begin]] + sorted_slice[begin]] = area / 2.0f;
+	}
+}
+
+// the same for one big slice per workgroup (see BIG_TASK)
+__global__ __launch_bounds__(BIG_THREADS) void k_slice_hulls_big(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
+                                                                 const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
+                                                                 const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
+                                                                 const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
+                                                                 const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count,
+                                                                 P2 *__restrict__ spill, float *__restrict__ areas) {
+	__shared__ P2 s_hull[2 * BIG_LDS];
+	__shared__ uint32_t s_first, s_se[2];
+	__shared__ P2 s_p;
+	if (blockIdx.x >= *big_count) return;
+	const uint32_t tid = threadIdx.x, t = big_list[blockIdx.x];
+	const uint32_t begin = task_start[t], end = t + 1u < n_tasks ? task_start[t + 1u] : n;
+	const uint32_t count = end - begin;
+	P2 *H = s_hull, *N = s_hull + BIG_LDS;
+	P2 *const big = spill + 2ull * begin + 4ull * t;
+	uint32_t cap = BIG_LDS, m = 0;
+	constexpr uint32_t NONE = 0xFFFFFFFFu;
+	auto normals = [&]() __attribute__((always_inline)) {
+		for (uint32_t c = 0; c < m; c += BIG_THREADS) {
+			const uint32_t j = c + tid;
+			if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+		}
+		__syncthreads();
+	};
+	// move H[src .. src + len) to H[dst ..): every thread reads its element before any thread writes, chunks in the
+	// direction that never overwrites an unread source
+	auto move = [&](uint32_t src, uint32_t dst, uint32_t len) __attribute__((always_inline)) {
+		if (src == dst || len == 0u) return;
+		const uint32_t chunks = (len + BIG_THREADS - 1u) / BIG_THREADS;
+		for (uint32_t q = 0; q < chunks; ++q) {
+			const uint32_t c = dst < src ? q : chunks - 1u - q;
+			const uint32_t k = c * BIG_THREADS + tid;
+			P2 v = {0.0f, 0.0f};
+			if (k < len) v = H[src + k];
+			__syncthreads();
+			if (k < len) H[dst + k] = v;
+			__syncthreads();
+		}
+	};
+	for (uint32_t base = 0; base < count; base += BIG_THREADS) {
+		const uint32_t i = base + tid;
+		bool pending = i < count;
+		P2 p = {0.0f, 0.0f};
+		if (pending) {
+			const uint32_t o = order[begin + i];
+			p.x = xyz[3ull * o + 0];
+			p.y = xyz[3ull * o + 2];
+			if (cls) pending = cls[o] == want;
+		}
+		for (;;) {
+			if (tid == 0) s_first = NONE;
+			__syncthreads();
+			bool has_s = false, has_e = false;
+			uint32_t st = 0, en = 0;
+			if (m == 0) { // Tree::new from the first point of the slice
+				if (pending) atomicMin(&s_first, tid);
+			} else {
+				bool last = edge_outside(H[m - 1u], N[m - 1u], p);
+				for (uint32_t j = 0; j < m; ++j) {
+					const bool out = edge_outside(H[j], N[j], p);
+					if (!last && out) {
+						st = j;
+						has_s = true;
+					} else if (last && !out) {
+						en = j;
+						has_e = true;
+					}
+					last = out;
+				}
+				if (pending && has_s && has_e) atomicMin(&s_first, tid);
+			}
+			__syncthreads();
+			const uint32_t f = s_first; // the first one in slice order (uniform)
+			if (f == NONE) break;
+			if (tid == f) {
+				s_se[0] = st;
+				s_se[1] = en;
+				s_p = p;
+			}
+			__syncthreads();
+			const uint32_t s0 = s_se[0], e0 = s_se[1];
+			const P2 np = s_p;
+			if (m == 0) {
+				if (tid == 0) {
+					H[0] = np;
+					H[1] = P2{np.x + 0.1f, np.y};
+					H[2] = P2{np.x, np.y + 0.1f};
+				}
+				m = 3;
+			} else if (e0 < s0) { // H' = H[e0 ..= s0] + [point]
+				const uint32_t keep = s0 - e0 + 1u;
+				move(e0, 0u, keep);
+				if (tid == 0) H[keep] = np;
+				m = keep + 1u;
+			} else { // H' = H[0 ..= s0] + [point] + H[e0 .. m)
+				const uint32_t tail = m - e0, dst = s0 + 2u;
+				if (dst + tail > cap) {
+					for (uint32_t c = 0; c < m; c += BIG_THREADS)
+						if (c + tid < m) big[c + tid] = H[c + tid];
+					__syncthreads();
+					H = big;
+					N = big + (count + 2u);
+					cap = NONE;
+				}
+				move(e0, dst, tail);
+				if (tid == 0) H[s0 + 1u] = np;
+				m = dst + tail;
+			}
+			pending = pending && tid > f;
+			__syncthreads();
+			normals();
+		}
+	}
+	if (tid == 0 && m >= 3u) {
+		float area = 0.0f;
+		const P2 a = H[0];
+		for (uint32_t i = 1; i + 1u < m; ++i) {
+			const P2 b = H[i], c = H[i + 1u];
+			const float bx = b.x - a.x, by = b.y - a.y, cx = c.x - a.x, cy = c.y - a.y;
+			area += bx * cy - by * cx;
+		}
+		areas[slice_off[sorted_seg[begin]] + sorted_slice[begin]] = area / 2.0f;
+	}
+}
+
+// ---- SegmentInformation::new (calculations.rs:210-276), one thread per segment --------------------------------------
+__global__ __launch_bounds__(256) void k_seg_info(const float *__restrict__ areas, const uint32_t *__restrict__ slice_off, const uint32_t *__restrict__ n_slices,
+                                                   const float *__restrict__ seg_min, const float *__restrict__ seg_max, uint32_t nseg, float *__restrict__ info) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= nseg) return;
+	const float *a = areas + slice_off[s];
+	const uint32_t slices = n_slices[s];
+	const float mn = seg_min[s * 3u + 1], mx = seg_max[s * 3u + 1];
+	const float ground_max_search_height = 1.0f, ground_min_area_scale = 1.5f, min_crown_diameter = 2.0f;
+	const uint32_t skip = as_usize_u32(1.0f / SLICE_WIDTH), take = as_usize_u32(10.0f / SLICE_WIDTH);
+	bool have = false;
+	float min_area = 0.5f;
+	for (uint32_t i = skip; i < slices && i < skip + take; ++i) // min_by(total_cmp): the first minimum
+		if (!have || f2total(a[i]) < f2total(min_area)) {
+			min_area = a[i];
+			have = true;
+		}
+	if (!have) min_area = 0.5f;
+	min_area = fmaxf(min_area, 0.5f);
+	const float thresh = min_area * ground_min_area_scale;
+	bool has_ground = false;
+	uint32_t ground = 0;
+	const uint32_t gtake = as_usize_u32(ground_max_search_height / SLICE_WIDTH);
+	for (uint32_t i = 0; i < slices && i < gtake; ++i)
+		if (a[i] > thresh) {
+			ground = i;
+			has_ground = true;
+			break;
+		}
+	uint32_t ground_sep = 0;
+	if (has_ground)
+		for (uint32_t i = ground; i < slices && i < slices / 2u; ++i)
+			if (a[i] < thresh) {
+				ground_sep = i;
+				break;
+			}
+	const float pi = 3.14159265358979323846f, half = min_crown_diameter / 2.0f;
+	const float min_crown_area = pi * (half * half);
+	uint32_t crown_sep = 0;
+	for (uint32_t i = ground_sep; i < slices; ++i)
+		if (a[i] > min_crown_area) {
+			crown_sep = i;
+			break;
+		}
+	const float ground_sep_f = mn + (float)ground_sep * SLICE_WIDTH;
+	const float crown_sep_f = mn + (float)crown_sep * SLICE_WIDTH;
+	info[s * 4u + 0] = crown_sep_f - ground_sep_f; // trunk_height
+	info[s * 4u + 1] = mx - crown_sep_f;           // crown_height
+	info[s * 4u + 2] = ground_sep_f;
+	info[s * 4u + 3] = crown_sep_f;
+}
+
+// SegmentData::new, classification (calculations.rs:149-163): 0 Ground, 1 Trunk, 2 Crown
+__global__ __launch_bounds__(256) void k_classify(const float *__restrict__ xyz, const uint32_t *__restrict__ seg, uint32_t n, const float *__restrict__ seg_max,
+                                                   const float *__restrict__ info, uint32_t *__restrict__ cls) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t sg = seg[i];
+	const float crown_sep = seg_max[sg * 3u + 1] - info[sg * 4u + 1];
+	const float ground_sep = crown_sep - info[sg * 4u + 0];
+	const float y = xyz[3ull * i + 1];
+	cls[i] = y < ground_sep ? 0u : (y < crown_sep ? 1u : 2u);
+}
+
+__device__ __forceinline__ float approximate_diameter(float area) { return 2.0f * sqrtf(area / 3.14159265358979323846f); } // calculations.rs:460-462
+
+// SegmentInformation::update (calculations.rs:303-313): slices[i] = diameter(area_i) / diameter(largest crown slice)
+__global__ __launch_bounds__(256) void k_seg_expansion(float *__restrict__ areas, const uint32_t *__restrict__ slice_off, const uint32_t *__restrict__ n_slices,
+                                                        const float *__restrict__ seg_min, const float *__restrict__ info, uint32_t nseg) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s >= nseg) return;
+	float *a = areas + slice_off[s];
+	const uint32_t slices = n_slices[s];
+	const uint32_t skip = as_usize_u32((info[s * 4u + 3] - seg_min[s * 3u + 1]) / SLICE_WIDTH);
+	bool have = false;
+	float crown_area = 0.0f;
+	for (uint32_t i = skip; i < slices; ++i) // max_by(total_cmp): the last maximum
+		if (!have || f2total(a[i]) >= f2total(crown_area)) {
+			crown_area = a[i];
+			have = true;
+		}
+	if (!have) crown_area = 0.0f;
+	const float crown_diameter = approximate_diameter(crown_area);
+	for (uint32_t i = 0; i < slices; ++i) a[i] = approximate_diameter(a[i]) / crown_diameter;
+}
+__global__ __launch_bounds__(256) void k_point_properties(const float *__restrict__ xyz, const uint32_t *__restrict__ seg, const uint32_t *__restrict__ slice,
+                                                           uint32_t n, const float *__restrict__ ratios, const uint32_t *__restrict__ slice_off,
+                                                           const float *__restrict__ seg_min, const float *__restrict__ seg_max,
+                                                           float *__restrict__ expansion, float *__restrict__ height) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t sg = seg[i];
+	const float mn = seg_min[sg * 3u + 1], mx = seg_max[sg * 3u + 1];
+	if (expansion) expansion[i] = ratios[slice_off[sg] + slice[i]];
+	if (height) height[i] = (xyz[3ull * i + 1] - mn) / (mx - mn);
+}
+
+// ---- DisplayData::new (interactive/mod.rs:1002-1039) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_i32(int32_t *__restrict__ p, uint32_t n, int32_t v) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(256) void k_seg_max_expansion(const float *__restrict__ expansion, const uint32_t *__restrict__ seg, uint32_t n,
+                                                            int32_t *__restrict__ best) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	atomicMax(&best[seg[i]], f2total(expansion[i])); // max_by(total_cmp): equal keys are identical bits
+}
+__device__ __forceinline__ uint32_t map_to_u32(float v) { // calculations.rs:455-457 (saturating cast, NaN -> 0)
+	const float x = v * 4294967296.0f;
+	if (!(x > 0.0f)) return 0u;
+	if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+	return (uint32_t)x;
+}
+__global__ __launch_bounds__(256) void k_display_values(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ cls, const float *__restrict__ curve,
+                                                         const float *__restrict__ expansion, const float *__restrict__ height, uint32_t n,
+                                                         const int32_t *__restrict__ best, uint32_t *__restrict__ cls_val, uint32_t *__restrict__ curve_val,
+                                                         uint32_t *__restrict__ exp_val, uint32_t *__restrict__ height_val) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	if (cls_val && cls) {
+		const uint32_t c = cls[i];
+		cls_val[i] = c == 0u ? 0xFFFFFFFFu / 8u : (c == 1u ? 0xFFFFFFFFu / 8u * 3u : 0xFFFFFFFFu / 8u * 6u);
+	}
+	if (curve_val && curve) curve_val[i] = map_to_u32(curve[i]);
+	if (height_val && height) height_val[i] = map_to_u32(height[i]);
+	if (exp_val && expansion) exp_val[i] = map_to_u32(expansion[i] / total2f(best[seg[i]]));
+}
+
+int bits_for(uint32_t count) {
+	int bits = 1;
+	while (bits < 32 && (1ull << bits) < count) ++bits;
+	return bits;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_seg, uint64_t n64, uint32_t nseg, float *d_seg_min,
+                                     float *d_seg_max, float *d_seg_info, uint32_t *d_cls, float *d_expansion, float *d_height) {
+	if (!ctx) return set_err(TREEE_ERR_INVALID, "treee_segments_calculate_dev: ctx is null");
+	if (nseg == 0 || nseg > (1u << 24)) return set_err(TREEE_ERR_INVALID, "n_segments %u outside [1, 2^24]", nseg);
+	if (n64 >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per shard", (unsigned long long)n64);
+	if (n64 && (!d_xyz || !d_seg)) return set_err(TREEE_ERR_INVALID, "treee_segments_calculate_dev: null array");
+	if (!d_seg_min || !d_seg_max || !d_seg_info) return set_err(TREEE_ERR_INVALID, "treee_segments_calculate_dev: null per-segment output");
+	if ((d_expansion || d_height) && !d_cls) return set_err(TREEE_ERR_INVALID, "expansion / height need the classification array");
+	const uint32_t n = (uint32_t)n64;
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	hipStream_t st = ctx->stream;
+	const uint32_t gn = div_up(n ? n : 1, 256), gs = div_up(nseg, 256);
+	uint32_t *d_err = nullptr, *d_seg_sorted = nullptr, *d_perm1 = nullptr, *d_start = nullptr, *d_aabb = nullptr, *d_nsl = nullptr, *d_sloff = nullptr;
+	uint32_t *d_total = nullptr;
+	const size_t cnt = n ? n : 1;
+	TREEE_TRY(ctx->alloc_t(4, &d_err));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_seg_sorted));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_perm1));
+	TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_start));
+	TREEE_TRY(ctx->alloc_t((size_t)nseg * 6, &d_aabb));
+	TREEE_TRY(ctx->alloc_t(nseg, &d_nsl));
+	TREEE_TRY(ctx->alloc_t(nseg, &d_sloff));
+	TREEE_TRY(ctx->alloc_t(4, &d_total));
+	TREEE_HIP(hipMemsetAsync(d_err, 0, 16, st));
+	const int sbits = bits_for(nseg);
+	// 1. min / max of every segment (SegmentData::new): segment order, wave-aggregated atomics
+	if (n) hipLaunchKernelGGL(k_check_segments, dim3(gn), dim3(256), 0, st, d_seg, n, nseg, d_err);
+	hipLaunchKernelGGL(k_init_aabb, dim3(div_up((uint64_t)nseg * 6, 256)), dim3(256), 0, st, d_aabb, nseg);
+	TREEE_LAUNCH_CHECK();
+	// (an id >= n_segments is reported below; the sort only looks at the low bits, the clamp keeps the kernels in range)
+	TREEE_TRY(sort_pairs_dev(ctx, d_seg, nullptr, n, sbits, d_seg_sorted, d_perm1));
+	{ // ids beyond the range would index past the per-segment arrays: stop here if any
+		TREEE_HIP(hipMemcpyAsync(ctx->h_scalars, d_err, 4, hipMemcpyDeviceToHost, st));
+		TREEE_HIP(hipStreamSynchronize(st));
+		if (ctx->h_scalars[0] & 1u) return set_err(TREEE_ERR_INVALID, "segment id >= n_segments (%u)", nseg);
+	}
+	hipLaunchKernelGGL(k_starts, dim3(div_up((uint64_t)nseg + 1, 256)), dim3(256), 0, st, d_seg_sorted, n, nseg, d_start);
+	if (n) hipLaunchKernelGGL(k_seg_aabb, dim3(gn), dim3(256), 0, st, d_xyz, d_perm1, d_seg_sorted, n, d_aabb);
+	hipLaunchKernelGGL(k_seg_finish_aabb, dim3(gs), dim3(256), 0, st, d_aabb, d_start, nseg, d_seg_min, d_seg_max, d_nsl, d_err);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_nsl, d_sloff, nseg, d_total));
+	// 2. final order = (segment, slice, input order): stable sort by slice, then by segment
+	uint32_t *d_slice = nullptr, *d_slice_s = nullptr, *d_permA = nullptr, *d_segA = nullptr, *d_segF = nullptr, *d_order = nullptr, *d_sliceF = nullptr;
+	uint32_t *d_flag = nullptr, *d_task_of = nullptr, *d_task_start = nullptr;
+	TREEE_TRY(ctx->alloc_t(cnt, &d_slice));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_slice_s));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_permA));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_segA));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_segF));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_order));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_sliceF));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_flag));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_task_of));
+	TREEE_TRY(ctx->alloc_t(cnt, &d_task_start));
+	uint32_t n_tasks = 0, total_slices = 0;
+	if (n) {
+		hipLaunchKernelGGL(k_slice_index, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, n, d_seg_min, d_nsl, d_slice);
+		TREEE_LAUNCH_CHECK();
+		TREEE_TRY(sort_pairs_dev(ctx, d_slice, nullptr, n, (int)SLICE_BITS, d_slice_s, d_permA));
+		hipLaunchKernelGGL(k_gather, dim3(gn), dim3(256), 0, st, d_seg, d_permA, n, d_segA);
+		TREEE_LAUNCH_CHECK();
+		TREEE_TRY(sort_pairs_dev(ctx, d_segA, d_permA, n, sbits, d_segF, d_order));
+		hipLaunchKernelGGL(k_gather, dim3(gn), dim3(256), 0, st, d_slice, d_order, n, d_sliceF);
+		hipLaunchKernelGGL(k_task_flags, dim3(gn), dim3(256), 0, st, d_segF, d_sliceF, n, d_flag);
+		TREEE_LAUNCH_CHECK();
+		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_flag, d_task_of, n, d_total + 1));
+		hipLaunchKernelGGL(k_task_starts, dim3(gn), dim3(256), 0, st, d_flag, d_task_of, n, d_task_start);
+		TREEE_LAUNCH_CHECK();
+	}
+	// the only other host round trip: how many slices and tasks there are (they size the next allocations)
+	TREEE_HIP(hipMemcpyAsync(ctx->h_scalars, d_total, 8, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipMemcpyAsync(ctx->h_scalars + 2, d_err, 4, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipStreamSynchronize(st));
+	total_slices = ctx->h_scalars[0];
+	n_tasks = n ? ctx->h_scalars[1] : 0u;
+	if (ctx->h_scalars[2] & 2u)
+		return set_err(TREEE_ERR_UNSUPPORTED, "a segment is taller than %u slices of %.1f m", (1u << SLICE_BITS) - 2u, (double)SLICE_WIDTH);
+	float *d_areas = nullptr;
+	P2 *d_spill = nullptr;
+	uint32_t *d_big = nullptr, *d_nbig = nullptr;
+	const uint32_t big_max = n / BIG_TASK + 1u; // no more slices than that can hold BIG_TASK points
+	TREEE_TRY(ctx->alloc_t(big_max, &d_big));
+	TREEE_TRY(ctx->alloc_t(4, &d_nbig));
+	TREEE_HIP(hipMemsetAsync(d_nbig, 0, 4, st));
+	if (n_tasks) hipLaunchKernelGGL(k_big_tasks, dim3(div_up(n_tasks, 256)), dim3(256), 0, st, d_task_start, n_tasks, n, d_big, d_nbig);
+	const uint32_t big_grid = n_tasks < big_max ? n_tasks : big_max;
+	TREEE_TRY(ctx->alloc_t((size_t)total_slices + 1, &d_areas));
+	TREEE_TRY(ctx->alloc_t(2 * (size_t)n + 4ull * n_tasks + 1, &d_spill));
+	// 3. get_size_areas over all points -> SegmentInformation::new -> classification
+	TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st)); // a slice without points has area 0.0
+	if (n_tasks) {
+		hipLaunchKernelGGL(k_slice_hulls_big, dim3(big_grid), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n, nullptr, 0u,
+		                   d_sloff, d_big, d_nbig, d_spill, d_areas); // the long ones first
+		hipLaunchKernelGGL(k_slice_hulls, dim3(div_up(n_tasks, 4)), dim3(256), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n, nullptr, 0u,
+		                   d_sloff, d_spill, d_areas);
+	}
+	hipLaunchKernelGGL(k_seg_info, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_max, nseg, d_seg_info);
+	if (n && d_cls) hipLaunchKernelGGL(k_classify, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, n, d_seg_max, d_seg_info, d_cls);
+	TREEE_LAUNCH_CHECK();
+	// 4. SegmentInformation::update: crown-only slice areas -> expansion; height
+	if (n && (d_expansion || d_height)) {
+		if (d_expansion) {
+			TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st));
+			hipLaunchKernelGGL(k_slice_hulls_big, dim3(big_grid), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n, d_cls, 2u,
+			                   d_sloff, d_big, d_nbig, d_spill, d_areas);
+			hipLaunchKernelGGL(k_slice_hulls, dim3(div_up(n_tasks, 4)), dim3(256), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n, d_cls, 2u,
+			                   d_sloff, d_spill, d_areas);
+			hipLaunchKernelGGL(k_seg_expansion, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_info, nseg);
+		}
+		hipLaunchKernelGGL(k_point_properties, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, d_slice, n, d_areas, d_sloff, d_seg_min, d_seg_max, d_expansion, d_height);
+		TREEE_LAUNCH_CHECK();
+	}
+	return TREEE_OK;
+}
+
+int32_t treee_display_values_dev(treee_ctx *ctx, const uint32_t *d_seg, uint64_t n64, uint32_t nseg, const uint32_t *d_cls, const float *d_curve,
+                                 const float *d_expansion, const float *d_height, uint32_t *d_cls_val, uint32_t *d_curve_val, uint32_t *d_exp_val,
+                                 uint32_t *d_height_val) {
+	if (!ctx) return set_err(TREEE_ERR_INVALID, "treee_display_values_dev: ctx is null");
+	if (n64 == 0) return TREEE_OK;
+	if (n64 >= (1ull << 32)) return set_err(TREEE_ERR_UNSUPPORTED, "n too large");
+	if (nseg == 0 || nseg > (1u << 24)) return set_err(TREEE_ERR_INVALID, "n_segments %u outside [1, 2^24]", nseg);
+	if (d_exp_val && (!d_expansion || !d_seg)) return set_err(TREEE_ERR_INVALID, "expansion values need the expansion and segment arrays");
+	const uint32_t n = (uint32_t)n64;
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	int32_t *d_best = nullptr;
+	TREEE_TRY(ctx->alloc_t(nseg, &d_best));
+	if (d_exp_val) {
+		// max_by(total_cmp).unwrap_or_default(): every queried segment has at least the querying point, so the start value
+		// (the smallest key of the total order) never survives where it is read
+		hipLaunchKernelGGL(k_init_i32, dim3(div_up(nseg, 256)), dim3(256), 0, ctx->stream, d_best, nseg, (int32_t)0x80000000);
+		hipLaunchKernelGGL(k_seg_max_expansion, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_expansion, d_seg, n, d_best);
+	}
+	hipLaunchKernelGGL(k_display_values, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_seg, d_cls, d_curve, d_expansion, d_height, n, d_best, d_cls_val,
+	                   d_curve_val, d_exp_val, d_height_val);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
+int32_t treee_segments_calculate(const float *xyz, const uint32_t *segment, uint64_t n, uint32_t n_segments, float *seg_min_out, float *seg_max_out,
+                                 float *seg_info_out, uint32_t *classification_out, float *expansion_out, float *height_out) {
+	if (n && (!xyz || !segment)) return set_err(TREEE_ERR_INVALID, "treee_segments_calculate: null argument");
+	if (!seg_min_out || !seg_max_out || !seg_info_out) return set_err(TREEE_ERR_INVALID, "treee_segments_calculate: null per-segment output");
+	if (n_segments == 0 || n_segments > (1u << 24)) return set_err(TREEE_ERR_INVALID, "n_segments %u outside [1, 2^24]", n_segments);
+	treee_ctx *ctx = nullptr;
+	TREEE_DEFAULT_CTX(ctx);
+	TREEE_HIP(hipSetDevice(ctx->device));
+	DevBuf<float> d_xyz, d_min, d_max, d_info, d_exp, d_hgt;
+	DevBuf<uint32_t> d_seg, d_cls;
+	TREEE_TRY(d_xyz.alloc(n * 3));
+	TREEE_TRY(d_seg.alloc(n));
+	TREEE_TRY(d_cls.alloc(n));
+	TREEE_TRY(d_min.alloc((size_t)n_segments * 3));
+	TREEE_TRY(d_max.alloc((size_t)n_segments * 3));
+	TREEE_TRY(d_info.alloc((size_t)n_segments * 4));
+	if (expansion_out) TREEE_TRY(d_exp.alloc(n));
+	if (height_out) TREEE_TRY(d_hgt.alloc(n));
+	if (n) {
+		TREEE_HIP(hipMemcpyAsync(d_xyz.p, xyz, n * 12, hipMemcpyHostToDevice, ctx->stream));
+		TREEE_HIP(hipMemcpyAsync(d_seg.p, segment, n * 4, hipMemcpyHostToDevice, ctx->stream));
+	}
+	TREEE_TRY(treee_segments_calculate_dev(ctx, d_xyz.p, d_seg.p, n, n_segments, d_min.p, d_max.p, d_info.p, d_cls.p, expansion_out ? d_exp.p : nullptr,
+	                                       height_out ? d_hgt.p : nullptr));
+	hipStream_t st = ctx->stream;
+	TREEE_HIP(hipMemcpyAsync(seg_min_out, d_min.p, (size_t)n_segments * 12, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipMemcpyAsync(seg_max_out, d_max.p, (size_t)n_segments * 12, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipMemcpyAsync(seg_info_out, d_info.p, (size_t)n_segments * 16, hipMemcpyDeviceToHost, st));
+	if (n && classification_out) TREEE_HIP(hipMemcpyAsync(classification_out, d_cls.p, n * 4, hipMemcpyDeviceToHost, st));
+	if (n && expansion_out) TREEE_HIP(hipMemcpyAsync(expansion_out, d_exp.p, n * 4, hipMemcpyDeviceToHost, st));
+	if (n && height_out) TREEE_HIP(hipMemcpyAsync(height_out, d_hgt.p, n * 4, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipStreamSynchronize(st));
+	return TREEE_OK;
+}
+
+} // extern "C"
