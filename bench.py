@@ -261,6 +261,7 @@ def main():
             out["hbm_copy_GBps"] = measured_copy_gbps(dev)
             out["ingest"] = ingest_stage(n, dev, ctx)
             out["per_segment_knn"] = segment_stage(pts, seg, ctx)
+            out["calculations"] = calculations_stage(pts, seg, ctx, cpu=not args.no_cpu_baseline)
             out["eye_dome"] = eye_dome_stage(depth, ctx)
             out["out_of_core"] = out_of_core_stage(dev, n, proj)
         if world == 1 and not args.no_cpu_baseline:
@@ -383,6 +384,56 @@ def segment_stage(pts, seg, ctx):
         "knn_curve_ms": round(res["curve"], 3),
         "Mpoints_per_s": round(n / ((res["build"] + res["curve"]) * 1e-3) / 1e6, 1),
     }
+
+
+def calculations_stage(pts, seg, ctx, cpu=True):
+    """SURVEY 8 F4, beside the step: the Calculations phase the curvature loop sits in -- SegmentData::new +
+    SegmentInformation::new / update (calculations.rs:133-327) and DisplayData::new (interactive/mod.rs:1002-1039) for
+    every segment of the same cloud (treee_segments_calculate_dev, treee_display_values_dev).  The CPU figure is the
+    oracle on the first segments of the cloud holding ~1.5 M points (the ground segment is among them), one thread per
+    segment the way Calculations::new spreads them over rayon (calculations.rs:97) -- wall time of the longest."""
+    import treee_amd as T
+
+    n = pts.shape[0]
+    nseg = int(seg.max().item()) + 1
+    curve = torch.rand((n,), dtype=torch.float32, device=pts.device)
+    ts, tv = [], []
+    for _ in range(3):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        r = T.segments_calculate(pts, seg, nseg, ctx=ctx)
+        e1.record()
+        T.display_values_dev(seg, nseg, r.classification, curve, r.expansion, r.height, ctx=ctx)
+        e2.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+        tv.append(e1.elapsed_time(e2))
+    out = {
+        "workload": f"{n} points in {nseg} segments: min/max, slice hulls (0.1 m), trunk/crown heights, classification, expansion, height; then the 4 display values",
+        "calculate_ms": round(min(ts[1:]), 3),
+        "display_values_ms": round(min(tv[1:]), 3),
+        "Mpoints_per_s": round(n / (min(ts[1:]) * 1e-3) / 1e6, 1),
+    }
+    if cpu:
+        from oracle import oracle as O
+
+        O.build()
+        sg = seg.cpu().numpy().astype(np.uint32)
+        host = pts.cpu().numpy()
+        counts = np.bincount(sg, minlength=nseg)
+        last = int(np.searchsorted(np.cumsum(counts), 1_500_000)) + 1
+        total, longest = 0, 0.0
+        t_all = time.perf_counter()
+        for s_id in range(min(last, nseg)):
+            q = host[sg == s_id]
+            t0 = time.perf_counter()
+            mn, mx, info, cls = O.segment_data(q)
+            O.segment_update(q, cls, mn[1], mx[1], info)
+            longest = max(longest, time.perf_counter() - t0)
+            total += len(q)
+        out["cpu_oracle"] = {"points": total, "segments": min(last, nseg), "one_thread_s": round(time.perf_counter() - t_all, 3),
+                             "longest_segment_s": round(longest, 3), "kind": "port"}
+    return out
 
 
 def out_of_core_stage(dev, n, proj, tiles=67):

@@ -72,6 +72,32 @@ def test_las_header_chunks_and_errors():
         Laz(img[:-5])
 
 
+def test_ply_and_segment_json_exports():
+    """save_points (interactive/mod.rs:1069-1103) and SegmentSave (:610-626): header, vertex filter by classification,
+    LAS axis order (x, -z, y), Rust `{}` float text (shortest round-trip digits, positional, no trailing .0)"""
+    import json
+
+    from treee_amd import export as E
+
+    assert [E.rust_display_f32(v) for v in (1.0, 0.1, -0.0, 1e-7, 16777216.0, np.nan, -np.inf, np.float32(0.1) + np.float32(0.2))] == [
+        "1", "0.1", "-0", "0.0000001", "16777216", "NaN", "-inf", "0.3"]
+    assert E.rust_display_f32(np.finfo(np.float32).max) == "340282350000000000000000000000000000000"
+    for v in np.random.default_rng(0).normal(0, 100, 200).astype(np.float32):  # shortest digits that read back exactly
+        t = E.rust_display_f32(v)
+        assert np.float32(t) == v and "e" not in t
+    pts = np.array([[1, 2, 3], [4, 5, 6], [7.5, 0.25, -0.125]], np.float32)
+    text = E.save_points(pts, [2, 1, 2], [0.5, 1.0, 0.75], [0.25, 0.75, 1.0], [np.nan, 0.1, 0.001], valid=E.CROWN)
+    lines = text.splitlines()
+    assert lines[:3] == ["ply", "format ascii 1.0", "element vertex 2"] and lines[9] == "end_header"
+    assert lines[3:9] == [f"property float {n}" for n in ("x", "y", "z", "expansion", "height", "curve")]
+    assert lines[10:] == ["1 -3 2 0.5 0.25 NaN", "7.5 0.125 0.25 0.75 1 0.001"]
+    assert E.save_points(pts, [2, 1, 2], [0, 0, 0], [0, 0, 0], [0, 0, 0]).splitlines()[2] == "element vertex 3"
+    d = json.loads(E.segment_save([9.8, 7.09, 0.273, 10.073], [-9.537, 0.273, -9.998], [1, 2, 3], [500000.5, 0, 12.25], longitude=13.4, latitude=52.5))
+    assert list(d) == ["trunk_height", "crown_height", "ground_sep", "crown_sep", "min", "max", "offset", "latitude", "longitude"]
+    assert d["trunk_height"] == 9.8 and d["min"] == [-9.537, 0.273, -9.998] and d["offset"] == [500000.5, 0.0, 12.25]
+    assert "latitude" not in json.loads(E.segment_save([0, 0, 0, 0], [0, 0, 0], [0, 0, 0], [0, 0, 0]))
+
+
 def test_camera_helpers():
     import treee_amd as T
 

@@ -102,10 +102,13 @@ __global__ __launch_bounds__(256) void k_seg_aabb(const float *__restrict__ xyz,
 				hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o, 64));
 			}
 		if ((threadIdx.x & 63u) == 0 && first != 0xFFFFFFFFu) {
+			// a plain read first: the stored extreme only ever moves outwards, so a wave that cannot improve even a stale
+			// copy of it has nothing to add -- without this the 47 000 waves of a plot's ground segment queue up on six words
+			volatile const uint32_t *cur = aabb + first * 6u;
 #pragma unroll
 			for (int d = 0; d < 3; ++d) {
-				if (lo[d] != 0xFFFFFFFFu) atomicMin(&aabb[first * 6u + d], lo[d]);
-				if (hi[d] != 0u) atomicMax(&aabb[first * 6u + 3u + d], hi[d]);
+				if (lo[d] < cur[d]) atomicMin(&aabb[first * 6u + d], lo[d]);
+				if (hi[d] > cur[3 + d]) atomicMax(&aabb[first * 6u + 3u + d], hi[d]);
 			}
 		}
 	} else if (live) {
@@ -260,7 +263,28 @@ __global__ __launch_bounds__(256) void k_slice_hulls(const float *__restrict__ x
 			uint32_t st = 0, en = 0;
 			{
 				bool last = edge_outside(H[m - 1u], N[m - 1u], p);
-				for (uint32_t j = 0; j < m; ++j) {
+				uint32_t j = 0;
+				for (; j + 4u <= m; j += 4u) { // four edges per trip: their eight reads are in flight together
+					P2 hv[4], nv[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						hv[u] = H[j + u];
+						nv[u] = N[j + u];
+					}
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const bool out = edge_outside(hv[u], nv[u], p);
+						if (!last && out) {
+							st = j + u;
+							has_s = true;
+						} else if (last && !out) {
+							en = j + u;
+							has_e = true;
+						}
+						last = out;
+					}
+				}
+				for (; j < m; ++j) {
 					const bool out = edge_outside(H[j], N[j], p);
 					if (!last && out) {
 						st = j;
@@ -404,7 +428,28 @@ __global__ __launch_bounds__(BIG_THREADS) void k_slice_hulls_big(const float *__
 				if (pending) atomicMin(&s_first, tid);
 			} else {
 				bool last = edge_outside(H[m - 1u], N[m - 1u], p);
-				for (uint32_t j = 0; j < m; ++j) {
+				uint32_t j = 0;
+				for (; j + 4u <= m; j += 4u) { // four edges per trip: their eight reads are in flight together
+					P2 hv[4], nv[4];
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						hv[u] = H[j + u];
+						nv[u] = N[j + u];
+					}
+#pragma unroll
+					for (int u = 0; u < 4; ++u) {
+						const bool out = edge_outside(hv[u], nv[u], p);
+						if (!last && out) {
+							st = j + u;
+							has_s = true;
+						} else if (last && !out) {
+							en = j + u;
+							has_e = true;
+						}
+						last = out;
+					}
+				}
+				for (; j < m; ++j) {
 					const bool out = edge_outside(H[j], N[j], p);
 					if (!last && out) {
 						st = j;
