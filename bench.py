@@ -471,15 +471,28 @@ def out_of_core_stage(dev, n, proj, tiles=67):
     return res
 
 
+def _latest_profile(pattern):
+    """newest committed summary profiles/rNN_vM_<pattern> (by round, then version)"""
+    import glob
+    import re
+
+    best, best_key = None, None
+    for path in glob.glob(os.path.join(ROOT, "profiles", f"r*_{pattern}")):
+        m = re.match(r"r(\d+)(?:_v(\d+))?_", os.path.basename(path))
+        if not m:
+            continue
+        key = (int(m.group(1)), int(m.group(2) or 0))
+        if best_key is None or key > best_key:
+            best, best_key = path, key
+    return best
+
+
 def measured_valu_busy(points):
     """What actually bounds the kernel (it is not HBM): fraction of SIMD cycles that issue a VALU instruction, from the
     committed SQ counters (profiles/knn_pmc.sh): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the share of ONE wave's lifetime,
     a SIMD holds 3 waves of this kernel."""
     try:
-        import glob
-
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v*_knn_sq_pmc.json")), key=lambda p: int(p.split("_v")[1].split("_")[0]))[-1]
-        c = json.load(open(path))
+        c = json.load(open(_latest_profile("knn_sq_pmc.json")))
         if points != 15_000_000:
             return None
         return round(3.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3)
@@ -489,10 +502,10 @@ def measured_valu_busy(points):
 
 def measured_traffic(points):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json: 2 x FETCH_SIZE raw, the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE);
+    (profiles/rNN[_vM]_traffic.json: 2 x FETCH_SIZE raw, the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE);
     only valid for the profiled size."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        t = json.load(open(_latest_profile("traffic.json")))
         if t["points_per_launch"] == points:
             return int(2 * t["fetch_size_bytes_raw"] + t["write_size_bytes"])
     except Exception:

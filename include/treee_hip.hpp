@@ -9,6 +9,7 @@
 //   k_nearest::Entry<f32>                                                                   k-nearest/src/kd_tree.rs:8-12
 //   NeighborsTree::{new, get}                                                               treee/src/calculations.rs:392-419
 //   the `curve` branch of SegmentInformation::update, map_to_u32                             treee/src/calculations.rs:328-373,455-457
+//   SegmentData::new, SegmentInformation::{new, update}, Classification (all segments at once) treee/src/calculations.rs:133-327
 //   render::PointCloud::render into a depth + id buffer, PointCloudEnvironment              render/src/point_cloud.rs:148-173,206-243
 //   Camera3D projection                                                                     render/src/camera_3d.rs:16-18
 //   laz::Chunk::read, the slice key of the load worker                                      treee/src/laz.rs:193-213, loading.rs:99
@@ -140,6 +141,43 @@ inline std::vector<float> curvature_segments(const std::vector<Point3> &data, co
 		check(treee_curvature_segments(data[0].data(), segment.data(), data.size(), n_segments, neighbors_count, neighbors_max_distance, curve.data()));
 	return curve;
 }
+// ---- the Calculations phase (calculations.rs:97-118): what `Shared.segments` holds afterwards, for all segments ----
+enum class Classification : uint32_t { Ground = 0, Trunk = 1, Crown = 2 }; // calculations.rs:45-58
+struct SegmentInformation {                                               // calculations.rs:190-197
+	float trunk_height, crown_height, ground_sep, crown_sep;
+};
+struct CalculationProperties { // calculations.rs:421-426 (curve: curvature_segments above)
+	std::vector<float> expansion, height;
+};
+struct SegmentsData { // SegmentData (calculations.rs:34-43) as a struct of arrays over the segments
+	std::vector<Point3> min, max;             // [n_segments]; an empty segment is (0, 0, 0)
+	std::vector<SegmentInformation> info;     // [n_segments]
+	std::vector<Classification> classifications; // [n], beside the points
+	CalculationProperties properties;         // SegmentInformation::update(calc_curve = false), [n] each
+};
+// SegmentData::new for every segment (`segment` = the Vec<u32> kept beside the points; a segment's points are taken in
+// the order they appear in `data`, the order of the reference's per-segment Vec), and SegmentInformation::update with
+// min / max = the segment's min.y / max.y (interactive/mod.rs:224-231) when `with_properties`
+inline SegmentsData segments_calculate(const std::vector<Point3> &data, const std::vector<uint32_t> &segment, uint32_t n_segments,
+                                       bool with_properties = true) {
+	if (segment.size() != data.size()) throw Error(TREEE_ERR_INVALID, "segment.len() != points.len()");
+	static_assert(sizeof(SegmentInformation) == 16 && sizeof(Classification) == 4, "layouts of the C ABI");
+	SegmentsData r;
+	r.min.resize(n_segments);
+	r.max.resize(n_segments);
+	r.info.resize(n_segments);
+	r.classifications.resize(data.size());
+	if (with_properties) {
+		r.properties.expansion.resize(data.size());
+		r.properties.height.resize(data.size());
+	}
+	check(treee_segments_calculate(data.empty() ? nullptr : data[0].data(), segment.data(), data.size(), n_segments,
+	                               n_segments ? r.min[0].data() : nullptr, n_segments ? r.max[0].data() : nullptr,
+	                               n_segments ? &r.info[0].trunk_height : nullptr, (uint32_t *)r.classifications.data(),
+	                               with_properties ? r.properties.expansion.data() : nullptr, with_properties ? r.properties.height.data() : nullptr));
+	return r;
+}
+
 // map_to_u32 (calculations.rs:455-457): (value * u32::MAX as f32) as u32, saturating like Rust's `as`
 inline uint32_t map_to_u32(float value) {
 	const float v = value * 4294967296.0f; // u32::MAX as f32 rounds to 2^32

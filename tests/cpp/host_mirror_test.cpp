@@ -139,6 +139,41 @@ int main() {
 				if (!std::isnan(w[i])) CHECK(std::fabs(both[where[i]] - w[i]) < 1e-4f);
 		}
 	}
+	// ---- SegmentData::new + SegmentInformation::new / update for all segments (calculations.rs:133-327) ---------
+	{
+		std::vector<uint32_t> segment(n);
+		for (size_t i = 0; i < n; ++i) segment[i] = points[i][0] < 10.0f ? 0u : (points[i][0] < 20.0f ? 1u : 3u); // segment 2 stays empty
+		const treee::SegmentsData got = treee::segments_calculate(points, segment, 4);
+		for (uint32_t sg = 0; sg < 4; ++sg) {
+			std::vector<Point3> part;
+			std::vector<size_t> where;
+			for (size_t i = 0; i < n; ++i)
+				if (segment[i] == sg) {
+					part.push_back(points[i]);
+					where.push_back(i);
+				}
+			float mn[3], mx[3], info[4];
+			std::vector<uint8_t> cls(part.size() + 1);
+			std::vector<float> ex(part.size() + 1), hg(part.size() + 1);
+			orc_segment_data(part.empty() ? nullptr : part[0].data(), part.size(), mn, mx, info, cls.data());
+			orc_segment_update(part.empty() ? nullptr : part[0].data(), cls.data(), part.size(), mn[1], mx[1], info, ex.data(), hg.data());
+			CHECK(std::memcmp(got.min[sg].data(), mn, 12) == 0 && std::memcmp(got.max[sg].data(), mx, 12) == 0);
+			CHECK(std::memcmp(&got.info[sg], info, 16) == 0);
+			size_t same = 0;
+			for (size_t i = 0; i < part.size(); ++i)
+				same += (uint32_t)got.classifications[where[i]] == cls[i] && std::memcmp(&got.properties.expansion[where[i]], &ex[i], 4) == 0 &&
+				        std::memcmp(&got.properties.height[where[i]], &hg[i], 4) == 0;
+			CHECK(same == part.size());
+		}
+		bool threw = false;
+		try {
+			segment.pop_back();
+			treee::segments_calculate(points, segment, 4);
+		} catch (const treee::Error &) {
+			threw = true;
+		}
+		CHECK(threw);
+	}
 	// ---- PointCloud::render into depth + id (point_cloud.rs:148-173, point_cloud.wgsl) --------------------
 	{
 		const uint32_t w = 160, h = 90;

@@ -622,7 +622,13 @@ __global__ __launch_bounds__(256) void k_seg_max_expansion(const float *__restri
                                                             int32_t *__restrict__ best) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
-	atomicMax(&best[seg[i]], f2total(expansion[i])); // max_by(total_cmp): equal keys are identical bits
+	// max_by(total_cmp): equal keys are identical bits.  A plain read first: the stored maximum only grows, so a value that
+	// does not beat even a stale copy of it has nothing to add (3 M points of a ground segment would otherwise queue up on
+	// one word); a wave whose lanes share the segment sends one atomic
+	const uint32_t sg = seg[i];
+	const int32_t key = f2total(expansion[i]);
+	if (key <= *(volatile const int32_t *)&best[sg]) return;
+	atomicMax(&best[sg], key);
 }
 __device__ __forceinline__ uint32_t map_to_u32(float v) { // calculations.rs:455-457 (saturating cast, NaN -> 0)
 	const float x = v * 4294967296.0f;
