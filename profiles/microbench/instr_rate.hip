@@ -190,6 +190,14 @@ template <int T> __global__ __launch_bounds__(1024) void k_rate(unsigned long lo
 #define X(i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(a4[i & 1]) : "v"(fa), "v"(fb));
 			TRIP(X)
 #undef X
+		} else if constexpr (T >= 60 && T <= 65) { // ds_write2st64_b32 under an exec mask
+			constexpr unsigned long long M = T == 60 ? ~0ull : T == 61 ? 1ull : T == 62 ? 0xFFFFull : T == 63 ? 0x1111111111111111ull : T == 64 ? 0x0001000100010001ull : 0ull;
+			const unsigned long long save = __builtin_amdgcn_read_exec();
+			asm volatile("s_mov_b64 exec, %0" : : "s"(M));
+#define X(i) asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:16" : : "v"(ofs), "v"(u[i]), "v"(w[i]) : "memory");
+			TRIP(X)
+#undef X
+			asm volatile("s_mov_b64 exec, %0" : : "s"(save));
 		} else if constexpr (T == 33) { // full 64-bit compare-exchange without f64: compare + 4 selects
 #define X(i) asm volatile("v_cmp_lt_u64 vcc, %0, %1\n\tv_cndmask_b32 %2, %2, %3, vcc\n\tv_cndmask_b32 %3, %3, %2, vcc\n\tv_cndmask_b32 %4, %4, %5, vcc\n\tv_cndmask_b32 %5, %5, %4, vcc" : "+v"(d[i]) : "v"(e[i]), "v"(u[i]), "v"(w[i]), "v"(f[i]), "v"(g[i]) : "vcc");
 			TRIP(X)
@@ -371,6 +379,12 @@ int main() {
 	run<47>("v_mul_f64", d_out);
 	run<41>("v_sub_f32 + v_mul_f32 dependent (2 instr)", d_out, 2);
 	run<34>("ds_bpermute_b32", d_out);
+	run<60>("ds_write2st64_b32 exec=all", d_out);
+	run<61>("ds_write2st64_b32 exec=1 lane", d_out);
+	run<62>("ds_write2st64_b32 exec=lanes 0-15", d_out);
+	run<63>("ds_write2st64_b32 exec=every 4th lane", d_out);
+	run<64>("ds_write2st64_b32 exec=every 16th lane", d_out);
+	run<65>("ds_write2st64_b32 exec=0", d_out);
 	run<10>("ds_write2st64_b32", d_out);
 	run<11>("ds_write_b32", d_out);
 	run<12>("ds_read_b64 (broadcast)", d_out);

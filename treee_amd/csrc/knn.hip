@@ -485,6 +485,9 @@ template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifndef TREEE_SCAN_PIPE
+#define TREEE_SCAN_PIPE 1
+#endif
 #ifndef TREEE_NBR
 #define TREEE_NBR 4 // Morton neighbours of the own bucket scanned before the tree walk (start-1, start+1, start-2, start+2); measured 0: 16.8 ms, 1: 12.8, 2: 11.6, 4: 11.5
 #endif
@@ -612,6 +615,41 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 	// candidates per instruction; the append is branch-free (write always, count if it passes)
 	auto scan_tile = [&](uint32_t base, uint64_t lanes, int first) __attribute__((always_inline)) {
 		const bool act = (lanes >> lane) & 1ull; // lanes outside `lanes` must not append (they saw this bucket already)
+#if TREEE_SCAN_PIPE
+		// software pipeline: the broadcast reads of the NEXT four candidates are issued as soon as this trip's distances
+		// exist (their registers are free again) and are in flight during the append -- the LDS round trip at the head
+		// of every trip is what a trip waits for
+		static_assert(SCHUNK == 4, "the pipelined scan reads 4 candidates per trip");
+		v4f nx = *(const v4f *)&tile[0][first], ny = *(const v4f *)&tile[1][first], nz = *(const v4f *)&tile[2][first];
+#pragma unroll 1
+		for (int c0 = first; c0 < BUCKET; c0 += SCHUNK) {
+			if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
+			uint32_t db[SCHUNK];
+			{
+				const v2f cx0 = {nx.x, nx.y}, cx1 = {nx.z, nx.w}, cy0 = {ny.x, ny.y}, cy1 = {ny.z, ny.w}, cz0 = {nz.x, nz.y}, cz1 = {nz.z, nz.w};
+				const v2f dx0 = cx0 - qx2, dy0 = cy0 - qy2, dz0 = cz0 - qz2, dx1 = cx1 - qx2, dy1 = cy1 - qy2, dz1 = cz1 - qz2;
+				const v2f d0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, d1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1; // metric.rs:21-26
+				db[0] = __float_as_uint(d0.x);
+				db[1] = __float_as_uint(d0.y);
+				db[2] = __float_as_uint(d1.x);
+				db[3] = __float_as_uint(d1.y);
+			}
+			{
+				const int cn = c0 + SCHUNK < BUCKET ? c0 + SCHUNK : c0; // (the last trip re-reads its own candidates: no branch)
+				nx = *(const v4f *)&tile[0][cn];
+				ny = *(const v4f *)&tile[1][cn];
+				nz = *(const v4f *)&tile[2][cn];
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // keeps the reads above the append
+			}
+#pragma unroll
+			for (int j = 0; j < SCHUNK; ++j) { // coarse filter; the merge applies the full (distance, position) order
+				char *w = (char *)buf + wofs;
+				*(uint32_t *)w = base + c0 + j;
+				*(uint32_t *)(w + DB_OFS) = db[j];
+				wofs += (db[j] <= thr && act) ? 256u : 0u;
+			}
+		}
+#else
 #pragma unroll 1
 		for (int c0 = first; c0 < BUCKET; c0 += SCHUNK) {
 			if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
@@ -634,6 +672,7 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 				wofs += (db[j] <= thr && act) ? 256u : 0u;
 			}
 		}
+#endif
 		__syncthreads();
 	};
 	auto scan_bucket = [&](uint32_t b) __attribute__((always_inline)) {
