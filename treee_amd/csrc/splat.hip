@@ -58,15 +58,19 @@ __device__ __forceinline__ bool footprint(const SplatParams &P, float x, float y
 	f.rx = fabsf(P.proj[0] * P.scale / w) * (0.5f * fw);
 	f.ry = fabsf(P.proj[5] * P.scale / w) * (0.5f * fh);
 	if (!(f.rx > 0.0f && f.ry > 0.0f)) return false;
-	f.x0 = clampi(floorf(f.sx - f.rx - 0.5f) - 1.0f, 0, (int)P.w);
-	f.x1 = clampi(ceilf(f.sx + f.rx - 0.5f) + 2.0f, 0, (int)P.w);
-	f.y0 = clampi(floorf(f.sy - f.ry - 0.5f) - 1.0f, 0, (int)P.h);
-	f.y1 = clampi(ceilf(f.sy + f.ry - 0.5f) + 2.0f, 0, (int)P.h);
+	// pixel px is covered only if sx - rx - 0.5 < px < sx + rx - 0.5; [floor(lower), ceil(upper) + 1) keeps one whole
+	// pixel of slack on either side (the rounding of these sums is < 0.002 px up to 16 K frames), and the coverage test
+	// below -- not this box -- decides: the result does not depend on the box as long as it is a superset
+	f.x0 = clampi(floorf(f.sx - f.rx - 0.5f), 0, (int)P.w);
+	f.x1 = clampi(ceilf(f.sx + f.rx - 0.5f) + 1.0f, 0, (int)P.w);
+	f.y0 = clampi(floorf(f.sy - f.ry - 0.5f), 0, (int)P.h);
+	f.y1 = clampi(ceilf(f.sy + f.ry - 0.5f) + 1.0f, 0, (int)P.h);
 	return f.x0 < f.x1 && f.y0 < f.y1;
 }
 
-__device__ __forceinline__ void plot(unsigned long long *packed, uint32_t w, const Foot &f, int px, int py, unsigned long long mine) {
-	const float v = (((float)py + 0.5f) - f.sy) / f.ry;
+__device__ __forceinline__ float row_v(const Foot &f, int py) { return (((float)py + 0.5f) - f.sy) / f.ry; }
+// v = row_v(f, py): the same for a whole row, so the caller computes it (and its IEEE divide) once per row
+__device__ __forceinline__ void plot(unsigned long long *packed, uint32_t w, const Foot &f, int px, int py, float v, unsigned long long mine) {
 	const float u = (((float)px + 0.5f) - f.sx) / f.rx;
 	if (!(u * u + v * v < 1.0f)) return; // point_cloud.wgsl:74-76
 	unsigned long long *p = packed + (size_t)py * w + px;
@@ -90,8 +94,11 @@ __global__ __launch_bounds__(256) void k_splat_points(const float *__restrict__ 
 		return;
 	}
 	const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + i);
-	for (int py = f.y0; py < f.y1; ++py)
-		for (int px = f.x0; px < f.x1; ++px) plot(packed, P.w, f, px, py, mine);
+	for (int py = f.y0; py < f.y1; ++py) {
+		const float v = row_v(f, py);
+		if (!(v * v < 1.0f)) continue; // (u * u >= 0: no pixel of this row can pass; NaN rows never pass either)
+		for (int px = f.x0; px < f.x1; ++px) plot(packed, P.w, f, px, py, v, mine);
+	}
 }
 
 __global__ __launch_bounds__(256) void k_splat_large(const float *__restrict__ xyz, const uint32_t *__restrict__ value,
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(256) void k_splat_large(const float *__restrict__ x
 		const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + i);
 		const int bw = f.x1 - f.x0;
 		const int area = bw * (f.y1 - f.y0);
-		for (int t = threadIdx.x; t < area; t += 256) plot(packed, P.w, f, f.x0 + t % bw, f.y0 + t / bw, mine);
+		for (int t = threadIdx.x; t < area; t += 256) plot(packed, P.w, f, f.x0 + t % bw, f.y0 + t / bw, row_v(f, f.y0 + t / bw), mine);
 	}
 }
 
