@@ -72,28 +72,52 @@ __global__ __launch_bounds__(256) void k_starts(const uint32_t *__restrict__ sor
 
 // ---- SegmentData::new, min / max (calculations.rs:135-147) --------------------------------------------------
 // f32::min / f32::max drop a NaN operand, so the result is the extreme of the non-NaN values: an order-independent
-// reduction.  Points come in segment order, so a wave usually holds one segment: it reduces with shuffles and lane 0
-// issues the six atomics; a wave that straddles a boundary lets every lane issue its own.
+// reduction.  Points come in segment order.  Pass 1: every wave reduces a tile of 256 consecutive points; a tile inside
+// one segment (nearly all) stores its six extremes without any atomic, a tile that straddles a boundary lets its lanes
+// update the segments' words directly.  Pass 2: one wave per segment folds the tiles inside its range into those
+// words.  (Atomics from every wave piled up: the first ~8 000 resident waves of a plot's ground segment all saw the
+// initial values and queued on six words -- 2.5 ms.)
+constexpr uint32_t AABB_TILE = 256;
 __global__ __launch_bounds__(256) void k_init_aabb(uint32_t *__restrict__ aabb, uint32_t nseg) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i < nseg * 6u) aabb[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u; // [s][0..2] = min (ordered image), [3..5] = max
 }
-__global__ __launch_bounds__(256) void k_seg_aabb(const float *__restrict__ xyz, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ sorted_seg,
-                                                   uint32_t n, uint32_t *__restrict__ aabb) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	const bool live = i < n;
-	const uint32_t sg = live ? sorted_seg[i] : 0xFFFFFFFFu;
+__global__ __launch_bounds__(256) void k_tile_aabb(const float *__restrict__ xyz, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ sorted_seg,
+                                                    uint32_t n, uint32_t *__restrict__ aabb, uint32_t *__restrict__ tiles /* [n_tiles][8]: 6 extremes, segment, pad */) {
+	const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	const uint32_t base = tile * AABB_TILE;
+	if (base >= n) return;
 	uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-	if (live) {
+	const uint32_t last = (base + AABB_TILE <= n ? base + AABB_TILE : n) - 1u;
+	const uint32_t s_first = sorted_seg[base], s_last = sorted_seg[last];
+	const bool uniform = s_first == s_last; // sorted: the whole tile is one segment
+#pragma unroll
+	for (uint32_t k = 0; k < AABB_TILE / 64u; ++k) {
+		const uint32_t i = base + k * 64u + lane;
+		if (i >= n) continue;
 		const uint32_t o = perm[i];
+		uint32_t vlo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, vhi[3] = {0u, 0u, 0u};
 #pragma unroll
 		for (int d = 0; d < 3; ++d) {
 			const float v = xyz[3ull * o + d];
-			if (v == v) lo[d] = hi[d] = f2ord(v);
+			if (v == v) vlo[d] = vhi[d] = f2ord(v);
+		}
+		if (uniform) {
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				lo[d] = min(lo[d], vlo[d]);
+				hi[d] = max(hi[d], vhi[d]);
+			}
+		} else { // a boundary tile (at most one per segment): straight into the segment's words
+			const uint32_t sg = sorted_seg[i];
+#pragma unroll
+			for (int d = 0; d < 3; ++d) {
+				if (vlo[d] != 0xFFFFFFFFu) atomicMin(&aabb[sg * 6u + d], vlo[d]);
+				if (vhi[d] != 0u) atomicMax(&aabb[sg * 6u + 3u + d], vhi[d]);
+			}
 		}
 	}
-	const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)sg);
-	if (__all(sg == first)) {
+	if (uniform) {
 #pragma unroll
 		for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -101,21 +125,47 @@ __global__ __launch_bounds__(256) void k_seg_aabb(const float *__restrict__ xyz,
 				lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o, 64));
 				hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o, 64));
 			}
-		if ((threadIdx.x & 63u) == 0 && first != 0xFFFFFFFFu) {
-			// a plain read first: the stored extreme only ever moves outwards, so a wave that cannot improve even a stale
-			// copy of it has nothing to add -- without this the 47 000 waves of a plot's ground segment queue up on six words
-			volatile const uint32_t *cur = aabb + first * 6u;
-#pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				if (lo[d] < cur[d]) atomicMin(&aabb[first * 6u + d], lo[d]);
-				if (hi[d] > cur[3 + d]) atomicMax(&aabb[first * 6u + 3u + d], hi[d]);
-			}
-		}
-	} else if (live) {
+	}
+	if (lane == 0) {
+		uint32_t *t = tiles + (size_t)tile * 8u;
+		t[0] = lo[0];
+		t[1] = lo[1];
+		t[2] = lo[2];
+		t[3] = hi[0];
+		t[4] = hi[1];
+		t[5] = hi[2];
+		t[6] = uniform ? s_first : 0xFFFFFFFFu; // boundary tiles are already accounted for
+	}
+}
+// one wave per segment: the tiles that lie inside [start[s], start[s + 1]) and belong to it
+__global__ __launch_bounds__(256) void k_seg_aabb(const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ start, uint32_t nseg,
+                                                   uint32_t *__restrict__ aabb) {
+	const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (s >= nseg) return;
+	const uint32_t b = start[s], e = start[s + 1u];
+	if (e == b) return;
+	uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+	for (uint32_t t = b / AABB_TILE + lane; t <= (e - 1u) / AABB_TILE; t += 64u) {
+		const uint32_t *q = tiles + (size_t)t * 8u;
+		if (q[6] != s) continue;
 #pragma unroll
 		for (int d = 0; d < 3; ++d) {
-			if (lo[d] != 0xFFFFFFFFu) atomicMin(&aabb[sg * 6u + d], lo[d]);
-			if (hi[d] != 0u) atomicMax(&aabb[sg * 6u + 3u + d], hi[d]);
+			lo[d] = min(lo[d], q[d]);
+			hi[d] = max(hi[d], q[3 + d]);
+		}
+	}
+#pragma unroll
+	for (int d = 0; d < 3; ++d)
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o, 64));
+			hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o, 64));
+		}
+	if (lane == 0) { // (the boundary tiles' atomics of pass 1 are complete: this kernel runs after it)
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			aabb[s * 6u + d] = min(aabb[s * 6u + d], lo[d]);
+			aabb[s * 6u + 3u + d] = max(aabb[s * 6u + 3u + d], hi[d]);
 		}
 	}
 }
@@ -171,7 +221,7 @@ __global__ __launch_bounds__(256) void k_task_starts(const uint32_t *__restrict_
 }
 
 // ---- Tree::new / insert / statistics for one (segment, slice) per wave -----------------------------------------
-constexpr uint32_t HULL_LDS = 512; // hull vertices kept in LDS per wave; a larger hull moves to the task's slot in HBM
+constexpr uint32_t HULL_LDS = 128; // hull vertices kept in LDS per wave; a larger hull moves to the task's slot in HBM
 
 struct P2 {
 	float x, y;
@@ -194,7 +244,7 @@ __device__ __forceinline__ bool edge_outside(P2 a, P2 nrm, P2 p) {
 
 // Slices of BIG_TASK points or more (the ground of a plot holds hundreds of thousands per slice) get a workgroup of 16
 // waves instead of one wave: 1024 points are tested per round, everything else is the same algorithm.
-constexpr uint32_t BIG_TASK = 2048, BIG_THREADS = 1024, BIG_LDS = 2048;
+constexpr uint32_t BIG_TASK = 2048, BIG_THREADS = 1024, BIG_LDS = 2048, BIG_PPT = 1;
 __global__ __launch_bounds__(256) void k_big_tasks(const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n, uint32_t *__restrict__ big_list,
                                                     uint32_t *__restrict__ big_count) {
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -204,19 +254,19 @@ __global__ __launch_bounds__(256) void k_big_tasks(const uint32_t *__restrict__ 
 }
 
 // one wave per task.  `cls` (optional): only points with cls[orig] == want take part (calculations.rs:299-301).
-__global__ __launch_bounds__(256) void k_slice_hulls(const float *__restrict__ xyz, const uint32_t *__restrict__ order /* final order -> original index */,
-                                                      const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
-                                                      const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
-                                                      const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
-                                                      P2 *__restrict__ spill /* [2 * n + 4 * n_tasks] */, float *__restrict__ areas) {
-	__shared__ P2 s_hull[4][2 * HULL_LDS]; // vertices, then the outward normal of the edge that starts at each vertex
-	const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const uint32_t t = blockIdx.x * 4u + w;
+__device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_LDS entries */, uint32_t t, const float *__restrict__ xyz,
+                                                const uint32_t *__restrict__ order /* final order -> original index */,
+                                                const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
+                                                const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
+                                                const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
+                                                P2 *__restrict__ spill /* [2 * n + 4 * n_tasks] */, float *__restrict__ areas) {
+	const uint32_t lane = threadIdx.x & 63u;
 	if (t >= n_tasks) return; // (whole waves leave: no block-wide barrier below)
 	const uint32_t begin = task_start[t], end = t + 1u < n_tasks ? task_start[t + 1u] : n;
 	const uint32_t count = end - begin;
-	if (count >= BIG_TASK) return; // a whole workgroup takes it (k_slice_hulls_big)
-	P2 *H = s_hull[w], *N = s_hull[w] + HULL_LDS;  // generic pointers: LDS first, HBM after an overflow
+	if (count >= BIG_TASK) return; // a whole workgroup takes it (slice_hull_block)
+	P2 *H = lds, *N = lds + HULL_LDS; // vertices, then the outward normal of the edge that starts at each vertex; generic
+	                                  // pointers: LDS first, HBM after an overflow
 	P2 *const big = spill + 2ull * begin + 4ull * t; // room for count + 2 vertices and as many normals
 	uint32_t cap = HULL_LDS, m = 0;                // m = hull size, 0 = no Tree yet
 	auto sync = [&]() __attribute__((always_inline)) { // the wave's own writes before its next reads
@@ -370,13 +420,12 @@ __global__ __launch_bounds__(256) void k_slice_hulls(const float *__restrict__ x
 }
 
 // the same for one big slice per workgroup (see BIG_TASK)
-__global__ __launch_bounds__(BIG_THREADS) void k_slice_hulls_big(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
-                                                                 const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
-                                                                 const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
-                                                                 const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
-                                                                 const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count,
-                                                                 P2 *__restrict__ spill, float *__restrict__ areas) {
-	__shared__ P2 s_hull[2 * BIG_LDS];
+__device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS entries */, const float *__restrict__ xyz, const uint32_t *__restrict__ order,
+                                                 const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
+                                                 const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
+                                                 const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
+                                                 const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count,
+                                                 P2 *__restrict__ spill, float *__restrict__ areas) {
 	__shared__ uint32_t s_first, s_se[2];
 	__shared__ P2 s_p;
 	if (blockIdx.x >= *big_count) return;
@@ -409,66 +458,105 @@ __global__ __launch_bounds__(BIG_THREADS) void k_slice_hulls_big(const float *__
 			__syncthreads();
 		}
 	};
-	for (uint32_t base = 0; base < count; base += BIG_THREADS) {
-		const uint32_t i = base + tid;
-		bool pending = i < count;
-		P2 p = {0.0f, 0.0f};
-		if (pending) {
-			const uint32_t o = order[begin + i];
-			p.x = xyz[3ull * o + 0];
-			p.y = xyz[3ull * o + 2];
-			if (cls) pending = cls[o] == want;
+	// BIG_PPT points per thread and round: an edge is read once for all of them, and a round that changes nothing -- most
+	// rounds of a long slice -- retires BIG_PPT * 1024 points.  Point r of a round (slice order) = j * BIG_THREADS + tid.
+	for (uint32_t base = 0; base < count; base += BIG_PPT * BIG_THREADS) {
+		bool pending[BIG_PPT];
+		P2 p[BIG_PPT];
+#pragma unroll
+		for (int j = 0; j < (int)BIG_PPT; ++j) {
+			const uint32_t i = base + (uint32_t)j * BIG_THREADS + tid;
+			pending[j] = i < count;
+			p[j] = P2{0.0f, 0.0f};
+			if (pending[j]) {
+				const uint32_t o = order[begin + i];
+				p[j].x = xyz[3ull * o + 0];
+				p[j].y = xyz[3ull * o + 2];
+				if (cls) pending[j] = cls[o] == want;
+			}
 		}
+		// rows [jlo, jhi) of the batch are tested in a round.  While the hull is still changing only the row of the last
+		// change is tested again (the rows before it are settled, testing the rows after it would be thrown away by the
+		// next change); once a row passes unchanged the window opens to the rest of the batch
+		uint32_t jlo = 0, jhi = 1;
 		for (;;) {
 			if (tid == 0) s_first = NONE;
 			__syncthreads();
-			bool has_s = false, has_e = false;
-			uint32_t st = 0, en = 0;
+			bool has_s[BIG_PPT], has_e[BIG_PPT];
+			uint32_t st[BIG_PPT], en[BIG_PPT];
+#pragma unroll
+			for (int j = 0; j < (int)BIG_PPT; ++j) {
+				has_s[j] = has_e[j] = false;
+				st[j] = en[j] = 0u;
+			}
 			if (m == 0) { // Tree::new from the first point of the slice
-				if (pending) atomicMin(&s_first, tid);
+#pragma unroll
+				for (int j = 0; j < (int)BIG_PPT; ++j)
+					if (pending[j]) atomicMin(&s_first, (uint32_t)j * BIG_THREADS + tid);
 			} else {
-				bool last = edge_outside(H[m - 1u], N[m - 1u], p);
-				uint32_t j = 0;
-				for (; j + 4u <= m; j += 4u) { // four edges per trip: their eight reads are in flight together
-					P2 hv[4], nv[4];
+				bool live[BIG_PPT], any = false;
 #pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						hv[u] = H[j + u];
-						nv[u] = N[j + u];
+				for (int j = 0; j < (int)BIG_PPT; ++j) {
+					live[j] = pending[j] && (uint32_t)j >= jlo && (uint32_t)j < jhi;
+					any = any || live[j];
+				}
+				if (any) { // (a thread with nothing to test skips the scan; the barriers below are outside)
+					bool last[BIG_PPT];
+					{
+						const P2 hl = H[m - 1u], nl = N[m - 1u];
+#pragma unroll
+						for (int j = 0; j < (int)BIG_PPT; ++j) last[j] = edge_outside(hl, nl, p[j]);
 					}
+					auto edge = [&](uint32_t e, P2 hv, P2 nv) __attribute__((always_inline)) {
 #pragma unroll
-					for (int u = 0; u < 4; ++u) {
-						const bool out = edge_outside(hv[u], nv[u], p);
-						if (!last && out) {
-							st = j + u;
-							has_s = true;
-						} else if (last && !out) {
-							en = j + u;
-							has_e = true;
+						for (int j = 0; j < (int)BIG_PPT; ++j) {
+							if ((uint32_t)j < jlo || (uint32_t)j >= jhi) continue; // uniform
+							const bool out = edge_outside(hv, nv, p[j]);
+							if (!last[j] && out) {
+								st[j] = e;
+								has_s[j] = true;
+							} else if (last[j] && !out) {
+								en[j] = e;
+								has_e[j] = true;
+							}
+							last[j] = out;
 						}
-						last = out;
+					};
+					uint32_t e = 0;
+					for (; e + 4u <= m; e += 4u) { // four edges per trip: their eight reads are in flight together
+						P2 hv[4], nv[4];
+#pragma unroll
+						for (int u = 0; u < 4; ++u) {
+							hv[u] = H[e + u];
+							nv[u] = N[e + u];
+						}
+#pragma unroll
+						for (int u = 0; u < 4; ++u) edge(e + u, hv[u], nv[u]);
 					}
+					for (; e < m; ++e) edge(e, H[e], N[e]);
+#pragma unroll
+					for (int j = 0; j < (int)BIG_PPT; ++j)
+						if (live[j] && has_s[j] && has_e[j]) atomicMin(&s_first, (uint32_t)j * BIG_THREADS + tid);
 				}
-				for (; j < m; ++j) {
-					const bool out = edge_outside(H[j], N[j], p);
-					if (!last && out) {
-						st = j;
-						has_s = true;
-					} else if (last && !out) {
-						en = j;
-						has_e = true;
-					}
-					last = out;
-				}
-				if (pending && has_s && has_e) atomicMin(&s_first, tid);
 			}
 			__syncthreads();
 			const uint32_t f = s_first; // the first one in slice order (uniform)
-			if (f == NONE) break;
-			if (tid == f) {
-				s_se[0] = st;
-				s_se[1] = en;
-				s_p = p;
+			if (f == NONE) {
+				if (m == 0 || jhi == BIG_PPT) break; // the whole batch is settled
+				jlo = jhi; // this window changed nothing: its rows are done, open the rest
+				jhi = BIG_PPT;
+				continue;
+			}
+			jlo = f / BIG_THREADS; // rows before the change are settled
+			jhi = jlo + 1u;
+			if (tid == f % BIG_THREADS) {
+#pragma unroll
+				for (int j = 0; j < (int)BIG_PPT; ++j)
+					if ((uint32_t)j == f / BIG_THREADS) {
+						s_se[0] = st[j];
+						s_se[1] = en[j];
+						s_p = p[j];
+					}
 			}
 			__syncthreads();
 			const uint32_t s0 = s_se[0], e0 = s_se[1];
@@ -499,7 +587,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_slice_hulls_big(const float *__
 				if (tid == 0) H[s0 + 1u] = np;
 				m = dst + tail;
 			}
-			pending = pending && tid > f;
+#pragma unroll
+			for (int j = 0; j < (int)BIG_PPT; ++j) pending[j] = pending[j] && (uint32_t)j * BIG_THREADS + tid > f;
 			__syncthreads();
 			normals();
 		}
@@ -513,6 +602,26 @@ __global__ __launch_bounds__(BIG_THREADS) void k_slice_hulls_big(const float *__
 			area += bx * cy - by * cx;
 		}
 		areas[slice_off[sorted_seg[begin]] + sorted_slice[begin]] = area / 2.0f;
+	}
+}
+
+// One launch for both kinds of slice: workgroups [0, big_max) take the big slices (those past *big_count leave at once;
+// being first in the grid, the long ones start first), the others take 16 ordinary slices each, one per wave.  As two
+// launches the ~20 workgroups of a plot's ground slices kept 236 CUs waiting for 3 ms.
+static_assert(2 * BIG_LDS == 16 * 2 * HULL_LDS, "both roles use the same 32 KiB of LDS");
+__global__ __launch_bounds__(BIG_THREADS) void k_slice_hulls(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
+                                                             const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
+                                                             const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
+                                                             const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
+                                                             const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count, uint32_t big_max,
+                                                             P2 *__restrict__ spill, float *__restrict__ areas) {
+	__shared__ P2 s_mem[2 * BIG_LDS];
+	if (blockIdx.x < big_max) {
+		slice_hull_block(s_mem, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want, slice_off, big_list, big_count, spill, areas);
+	} else {
+		const uint32_t w = threadIdx.x >> 6;
+		slice_hull_wave(s_mem + w * 2u * HULL_LDS, (blockIdx.x - big_max) * 16u + w, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want,
+		                slice_off, spill, areas);
 	}
 }
 
@@ -699,7 +808,13 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 		if (ctx->h_scalars[0] & 1u) return set_err(TREEE_ERR_INVALID, "segment id >= n_segments (%u)", nseg);
 	}
 	hipLaunchKernelGGL(k_starts, dim3(div_up((uint64_t)nseg + 1, 256)), dim3(256), 0, st, d_seg_sorted, n, nseg, d_start);
-	if (n) hipLaunchKernelGGL(k_seg_aabb, dim3(gn), dim3(256), 0, st, d_xyz, d_perm1, d_seg_sorted, n, d_aabb);
+	if (n) {
+		const uint32_t n_tiles = div_up(n, AABB_TILE);
+		uint32_t *d_tiles = nullptr;
+		TREEE_TRY(ctx->alloc_t((size_t)n_tiles * 8, &d_tiles));
+		hipLaunchKernelGGL(k_tile_aabb, dim3(div_up(n_tiles, 4)), dim3(256), 0, st, d_xyz, d_perm1, d_seg_sorted, n, d_aabb, d_tiles);
+		hipLaunchKernelGGL(k_seg_aabb, dim3(div_up(nseg, 4)), dim3(256), 0, st, d_tiles, d_start, nseg, d_aabb);
+	}
 	hipLaunchKernelGGL(k_seg_finish_aabb, dim3(gs), dim3(256), 0, st, d_aabb, d_start, nseg, d_seg_min, d_seg_max, d_nsl, d_err);
 	TREEE_LAUNCH_CHECK();
 	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_nsl, d_sloff, nseg, d_total));
@@ -752,12 +867,9 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	TREEE_TRY(ctx->alloc_t(2 * (size_t)n + 4ull * n_tasks + 1, &d_spill));
 	// 3. get_size_areas over all points -> SegmentInformation::new -> classification
 	TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st)); // a slice without points has area 0.0
-	if (n_tasks) {
-		hipLaunchKernelGGL(k_slice_hulls_big, dim3(big_grid), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n, nullptr, 0u,
-		                   d_sloff, d_big, d_nbig, d_spill, d_areas); // the long ones first
-		hipLaunchKernelGGL(k_slice_hulls, dim3(div_up(n_tasks, 4)), dim3(256), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n, nullptr, 0u,
-		                   d_sloff, d_spill, d_areas);
-	}
+	if (n_tasks)
+		hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 16)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
+		                   nullptr, 0u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_areas);
 	hipLaunchKernelGGL(k_seg_info, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_max, nseg, d_seg_info);
 	if (n && d_cls) hipLaunchKernelGGL(k_classify, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, n, d_seg_max, d_seg_info, d_cls);
 	TREEE_LAUNCH_CHECK();
@@ -765,10 +877,8 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	if (n && (d_expansion || d_height)) {
 		if (d_expansion) {
 			TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st));
-			hipLaunchKernelGGL(k_slice_hulls_big, dim3(big_grid), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n, d_cls, 2u,
-			                   d_sloff, d_big, d_nbig, d_spill, d_areas);
-			hipLaunchKernelGGL(k_slice_hulls, dim3(div_up(n_tasks, 4)), dim3(256), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n, d_cls, 2u,
-			                   d_sloff, d_spill, d_areas);
+			hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 16)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
+			                   d_cls, 2u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_areas);
 			hipLaunchKernelGGL(k_seg_expansion, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_info, nseg);
 		}
 		hipLaunchKernelGGL(k_point_properties, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, d_slice, n, d_areas, d_sloff, d_seg_min, d_seg_max, d_expansion, d_height);
