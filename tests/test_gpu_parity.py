@@ -1240,3 +1240,48 @@ def test_display_values_vs_oracle(T, oracle):
                                             T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1), w, h)
     seen = set(np.unique(ids.cpu().numpy().view(np.uint32))) - {0}
     assert seen <= {0xFFFFFFFF // 8, 0xFFFFFFFF // 8 * 3, 0xFFFFFFFF // 8 * 6} and len(seen) >= 2
+
+
+def test_full_size_15m_calculations_properties(T, oracle):
+    """the Calculations phase at the bench's size (15 M points, 2 501 segments): size-independent properties over the
+    whole cloud -- min / max against torch's segmented reductions (exact), the classification against the separators,
+    height in [0, 1], expansion 0 outside the crown and 1 in the widest crown slice of every tree -- and sampled
+    segments (the 3 M-point ground among them: the workgroup-per-slice kernel at full length) bit for bit against the
+    CPU restatement."""
+    import torch
+
+    from treee_amd import synth
+
+    n = 15_000_000
+    d_pts, d_seg = synth.forest_cloud_torch(n, "cuda")
+    S = int(d_seg.max().item()) + 1
+    r = T.segments_calculate(d_pts, d_seg, S)
+    torch.cuda.synchronize()
+    sl = d_seg.long()
+    for dim in range(3):
+        col = d_pts[:, dim].contiguous()
+        mn = torch.full((S,), float("inf"), device="cuda").scatter_reduce(0, sl, col, "amin")
+        mx = torch.full((S,), float("-inf"), device="cuda").scatter_reduce(0, sl, col, "amax")
+        assert torch.equal(r.min[:, dim], mn) and torch.equal(r.max[:, dim], mx)
+    info, y = r.info, d_pts[:, 1]
+    crown_sep = (r.max[:, 1] - info[:, 1])[sl]
+    ground_sep = (r.max[:, 1] - info[:, 1] - info[:, 0])[sl]
+    want_cls = torch.where(y < ground_sep, 0, torch.where(y < crown_sep, 1, 2)).to(r.classification.dtype)
+    assert torch.equal(r.classification, want_cls)
+    assert float(r.height.min()) == 0.0 and float(r.height.max()) == 1.0
+    e = r.expansion
+    assert bool(((e >= 0) & (e <= 1))[~torch.isnan(e)].all())
+    trees = torch.arange(1, S, device="cuda")
+    seg_max_e = torch.zeros((S,), device="cuda").scatter_reduce(0, sl, torch.nan_to_num(e), "amax")
+    assert bool((seg_max_e[trees] == 1.0).all())  # every tree has its widest crown slice
+    assert float((info[1:, 0] > 2.0).float().mean()) > 0.95 and float((info[1:, 1] > 2.0).float().mean()) > 0.95  # trunks and crowns
+    seg = d_seg.cpu().numpy()
+    for sg in (0, 1, 1234, S - 1):
+        sel = torch.from_numpy(np.nonzero(seg == sg)[0]).cuda()
+        q = d_pts[sel].cpu().numpy()
+        mn_o, mx_o, info_o, cls_o = oracle.segment_data(q)
+        e_o, h_o = oracle.segment_update(q, cls_o, mn_o[1], mx_o[1], info_o)
+        assert np.array_equal(info[sg].cpu().numpy().view(np.uint32), info_o.view(np.uint32))
+        assert np.array_equal(r.classification[sel].cpu().numpy().astype(np.uint8), cls_o)
+        assert np.array_equal(r.expansion[sel].cpu().numpy().view(np.uint32), e_o.view(np.uint32))
+        assert np.array_equal(r.height[sel].cpu().numpy().view(np.uint32), h_o.view(np.uint32))
