@@ -1285,3 +1285,38 @@ def test_full_size_15m_calculations_properties(T, oracle):
         assert np.array_equal(r.classification[sel].cpu().numpy().astype(np.uint8), cls_o)
         assert np.array_equal(r.expansion[sel].cpu().numpy().view(np.uint32), e_o.view(np.uint32))
         assert np.array_equal(r.height[sel].cpu().numpy().view(np.uint32), h_o.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_segments_calculate_fuzz_vs_oracle(T, oracle, seed):
+    """random segment layouts, sizes and shapes -- lattice points (exact collinearity, duplicates, on-edge points: the
+    strict `> 0` of segmenting.rs:352 decides), thin sticks, flat pancakes, single points, empty segments, random segment
+    order in memory -- against the per-segment CPU restatement, everything bit for bit"""
+    rng = np.random.default_rng(seed)
+    S = int(rng.integers(3, 40))
+    parts, ids = [], []
+    for sg in range(S):
+        kind = rng.integers(0, 6)
+        n = int(rng.integers(0, 4000)) if kind else 0
+        if n == 0:
+            continue
+        c = rng.uniform(-50, 50, 3)
+        if kind == 1:  # lattice: many exact ties
+            q = c + rng.integers(-6, 7, (n, 3)) * np.array([0.25, 0.05, 0.25])
+        elif kind == 2:  # stick
+            q = c + rng.normal(0, 0.02, (n, 3)) + np.outer(rng.uniform(0, 12, n), [0, 1, 0])
+        elif kind == 3:  # pancake: one or two slices with many points
+            q = c + rng.normal(0, 2.5, (n, 3)) * np.array([1, 0.02, 1])
+        elif kind == 4:  # tree-like
+            h = rng.uniform(0, 15, n)
+            r = np.where(h > 7, rng.uniform(0, 2.5, n), rng.uniform(0, 0.2, n))
+            a = rng.uniform(0, 2 * np.pi, n)
+            q = c + np.stack([r * np.cos(a), h, r * np.sin(a)], 1)
+        else:  # single point repeated a few times
+            q = np.repeat(c[None, :], min(n, 7), 0)
+        parts.append(q)
+        ids.append(np.full(len(q), sg))
+    pts = np.concatenate(parts).astype(np.float32)
+    seg = np.concatenate(ids).astype(np.uint32)
+    perm = rng.permutation(len(pts))  # segments interleaved in memory: only the order inside a segment matters
+    _check_segments_against_oracle(T, oracle, pts[perm], seg[perm], S, device=bool(seed & 1))
