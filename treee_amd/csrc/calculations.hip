@@ -20,8 +20,6 @@
 // `segments: HashMap<u32, Vec<Point3<f32>>>` vectors): two stable radix sorts (slice, then segment) keep it.
 #include "common.h"
 
-#include <cstdlib>
-
 using namespace treee;
 
 namespace {
@@ -865,6 +863,24 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	TREEE_HIP(hipMemsetAsync(d_nbig, 0, 4, st));
 	if (n_tasks) hipLaunchKernelGGL(k_big_tasks, dim3(div_up(n_tasks, 256)), dim3(256), 0, st, d_task_start, n_tasks, n, d_big, d_nbig);
 	const uint32_t big_grid = n_tasks < big_max ? n_tasks : big_max;
+	TREEE_TRY(ctx->alloc_t((size_t)total_slices + 1, &d_areas));
+	TREEE_TRY(ctx->alloc_t(2 * (size_t)n + 4ull * n_tasks + 1, &d_spill));
+	// 3. get_size_areas over all points -> SegmentInformation::new -> classification
+	TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st)); // a slice without points has area 0.0
+	if (n_tasks)
+		hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 16)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
+		                   nullptr, 0u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_areas);
+	hipLaunchKernelGGL(k_seg_info, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_max, nseg, d_seg_info);
+	if (n && d_cls) hipLaunchKernelGGL(k_classify, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, n, d_seg_max, d_seg_info, d_cls);
+	TREEE_LAUNCH_CHECK();
+	// 4. SegmentInformation::update: crown-only slice areas -> expansion; height
+	if (n && (d_expansion || d_height)) {
+		if (d_expansion) {
+			TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st));
+			hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 16)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
+			                   d_cls, 2u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_areas);
+			hipLaunchKernelGGL(k_seg_expansion, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_info, nseg);
+		}
 		hipLaunchKernelGGL(k_point_properties, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, d_slice, n, d_areas, d_sloff, d_seg_min, d_seg_max, d_expansion, d_height);
 		TREEE_LAUNCH_CHECK();
 	}
