@@ -181,6 +181,15 @@ int32_t treee_sort_build(const float *xyz_aos, uint64_t n, const float corner[3]
 int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n,
                              const float corner[3], float size, uint32_t leaf_cap,
                              uint32_t lod_cap, treee_octree **out);
+/* The two halves of treee_sort_build_dev as separate calls.  treee_sort_dev: the Morton sort alone -- a handle whose
+ * sorted arrays (KEYS, PERM, SORTED_XYZ) exist and whose node table does not yet (n_nodes = 0); it synchronises once (the
+ * cube when it is computed from the data, and the crowded-cell flag a kNN structure needs) and
+ * treee_knn_from_octree_dev accepts it.  treee_octree_complete_dev builds the node table, leaf ids and LOD lists later,
+ * on ANY context of the same device: on a context bound to a second stream the octree's ~50 small launches run under
+ * the kNN kernel of the first (the library orders the streams, see "Streams").  One handle, freed once. */
+int32_t treee_sort_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, const float corner[3], float size,
+                       treee_octree **out);
+int32_t treee_octree_complete_dev(treee_ctx *ctx, treee_octree *o, uint32_t leaf_cap, uint32_t lod_cap);
 int32_t treee_octree_free(treee_octree *o);
 typedef struct {
 	uint64_t n_points, n_nodes, n_lod;

@@ -1320,3 +1320,39 @@ def test_segments_calculate_fuzz_vs_oracle(T, oracle, seed):
     seg = np.concatenate(ids).astype(np.uint32)
     perm = rng.permutation(len(pts))  # segments interleaved in memory: only the order inside a segment matters
     _check_segments_against_oracle(T, oracle, pts[perm], seg[perm], S, device=bool(seed & 1))
+
+
+def test_deferred_octree_on_a_second_stream(T, oracle):
+    """treee_sort_dev + treee_octree_complete_dev: the node table built later, on a context of another stream while a kNN
+    kernel over the same sorted cloud runs on the first, is bit for bit the one-call build; the kNN structure taken from
+    the sort-only handle gives the one-call result; freeing in either order is safe"""
+    import torch
+
+    from treee_amd import synth
+
+    pts, _ = synth.forest_cloud(400_000, plot=33.0)
+    d = torch.from_numpy(pts).cuda()
+    ref = T.Octree(d, leaf_cap=64, lod_cap=32)
+    ref_tree = T.KDTree.from_octree(ref)
+    ref_dist, ref_idx, ref_cnt = ref_tree.self_neighbors_dev(31)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    ctx_side = T.Context(d.device, side)
+    for free_tree_first in (True, False):
+        oc = T.Octree(d, leaf_cap=64, lod_cap=32, defer=True)
+        assert oc.n_nodes == 0 and np.array_equal(oc.array("keys"), ref.array("keys")) and np.array_equal(oc.corner, ref.corner)
+        tree = T.KDTree.from_octree(oc)
+        dist, idx, cnt = tree.self_neighbors_dev(31)  # long kernel on the first stream ...
+        oc.complete(ctx_side)  # ... the octree on the second, under it
+        assert oc.n_nodes == ref.n_nodes and oc.n_lod == ref.n_lod
+        for name in ("nodes", "leaf", "lod", "perm", "keys"):
+            assert np.array_equal(oc.array(name).view(np.uint32), ref.array(name).view(np.uint32)), name
+        torch.cuda.synchronize()
+        assert torch.equal(dist.view(torch.int32), ref_dist.view(torch.int32)) and torch.equal(idx, ref_idx) and torch.equal(cnt, ref_cnt)
+        with pytest.raises(T.TreeeError):
+            T._lib.check(T.lib().treee_octree_complete_dev(ctx_side.handle, oc._h, 64, 32))  # already complete
+        (tree if free_tree_first else oc).close()
+        (oc if free_tree_first else tree).close()
+    ref_tree.close()
+    ref.close()
+    ctx_side.sync()

@@ -66,6 +66,8 @@ SYMBOLS = {
     "treee_map_to_u32_dev": (_i32, [_vp, _vp, _u64, _vp]),
     "treee_sort_build": (_i32, [_vp, _u64, _vp, _f32, _u32, _u32, _pp]),
     "treee_sort_build_dev": (_i32, [_vp, _vp, _u64, _vp, _f32, _u32, _u32, _pp]),
+    "treee_sort_dev": (_i32, [_vp, _vp, _u64, _vp, _f32, _pp]),
+    "treee_octree_complete_dev": (_i32, [_vp, _vp, _u32, _u32]),
     "treee_octree_free": (_i32, [_vp]),
     "treee_octree_info_get": (_i32, [_vp, C.POINTER(OctreeInfo)]),
     "treee_octree_copy": (_i32, [_vp, _i32, _vp, _u64]),

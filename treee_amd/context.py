@@ -50,7 +50,12 @@ class Context:
 
         if not torch.cuda.is_available():
             raise _lib.TreeeError(_lib.TREEE_ERR_HIP, "no HIP device visible to torch; treee_amd has no CPU fallback")
-        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if device is None:
+            device = torch.cuda.current_device()
+        elif not isinstance(device, int):  # a torch.device or "cuda:N"
+            idx = torch.device(device).index
+            device = torch.cuda.current_device() if idx is None else idx
+        self.device = torch.device("cuda", device)
         with torch.cuda.device(self.device):
             s = torch.cuda.current_stream() if stream is None else stream
         self.stream = s

@@ -101,6 +101,16 @@ struct treee_ctx {
 	std::unordered_map<void *, size_t> pool_live;
 	std::mutex pool_mu;
 
+	// Fork / join inside one API call: independent work (the octree's ~50 small launches next to the record gather) runs
+	// on an auxiliary stream of the context.  fork(): aux waits for what `stream` holds so far.  on_aux(true/false):
+	// launches of the internal stage functions go to aux / back to `stream`.  join(): `stream` waits for aux.  Every
+	// build joins before it returns, so outside an API call the context has exactly one stream, as documented.
+	hipStream_t aux = nullptr, main_stream = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	int32_t fork();
+	void on_aux(bool yes);
+	int32_t join();
+
 	int32_t reset();                         // start of an API call: coalesce + rewind
 	int32_t alloc(size_t bytes, void **out); // 256-B aligned
 	template <class T> int32_t alloc_t(size_t count, T **out) {
@@ -124,12 +134,15 @@ namespace treee {
 struct HandleSync {
 	std::mutex mu;
 	std::vector<std::pair<hipStream_t, hipEvent_t>> users; // last use per foreign stream
+	hipEvent_t ready = nullptr; // optional: "the arrays are complete", recorded on the owner's stream by mark_ready.  With it
+	                            // a foreign stream waits for the build only, not for what the owner enqueued afterwards
 	HandleSync() = default;
 	HandleSync(const HandleSync &) = delete;
 	HandleSync &operator=(const HandleSync &) = delete;
 	~HandleSync();
 };
 bool ctx_is_live(treee_ctx *ctx);
+int32_t mark_ready(treee_ctx *owner, HandleSync *hs);
 int32_t use_begin(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs);
 int32_t use_end(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs);
 void retire(treee_ctx *owner, HandleSync *hs);
@@ -185,7 +198,7 @@ struct SortedCloud {
 // the sorted cloud of an octree can be shared with a kNN structure (one sort, two consumers)
 std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o);
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner,
-                           float size, SortedCloud *out);
+                           float size, SortedCloud *out, bool fork_after_sort = false);
 // *d_flag (device, zeroed here) = 1 iff sorted keys hold a run of more than LONG_RUN equal keys
 #ifndef TREEE_LONG_RUN
 #define TREEE_LONG_RUN 256

@@ -89,8 +89,22 @@ bool ctx_is_live(treee_ctx *ctx) {
 
 static bool foreign(treee_ctx *ctx, treee_ctx *owner) { return ctx && owner && ctx != owner && ctx->stream != owner->stream; }
 
-int32_t use_begin(treee_ctx *ctx, treee_ctx *owner, HandleSync *) {
+int32_t mark_ready(treee_ctx *owner, HandleSync *hs) {
+	std::lock_guard<std::mutex> lk(hs->mu);
+	if (!hs->ready) TREEE_HIP(hipEventCreateWithFlags(&hs->ready, hipEventDisableTiming));
+	TREEE_HIP(hipEventRecord(hs->ready, owner->stream));
+	return TREEE_OK;
+}
+
+int32_t use_begin(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs) {
 	if (!foreign(ctx, owner) || !ctx_is_live(owner)) return TREEE_OK; // (a destroyed owner synchronised its stream: the build is done)
+	{
+		std::lock_guard<std::mutex> lk(hs->mu);
+		if (hs->ready) { // the build's own event: later work of the owner's stream (a kNN kernel, say) is not waited for
+			TREEE_HIP(hipStreamWaitEvent(ctx->stream, hs->ready, 0));
+			return TREEE_OK;
+		}
+	}
 	hipEvent_t ev = nullptr;
 	TREEE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 	hipError_t e = hipEventRecord(ev, owner->stream);
@@ -124,9 +138,14 @@ void retire(treee_ctx *owner, HandleSync *hs) {
 		(void)hipEventDestroy(u.second);
 	}
 	hs->users.clear();
+	if (hs->ready) {
+		(void)hipEventDestroy(hs->ready); // (destroying a recorded event does not disturb waits already enqueued on it)
+		hs->ready = nullptr;
+	}
 }
 
 HandleSync::~HandleSync() {
+	if (ready) (void)hipEventDestroy(ready);
 	for (auto &u : users) {
 		(void)hipEventSynchronize(u.second);
 		(void)hipEventDestroy(u.second);
@@ -159,6 +178,32 @@ int32_t default_ctx(treee_ctx **out) {
 } // namespace treee
 
 using namespace treee;
+
+int32_t treee_ctx::fork() {
+	if (!aux) {
+		TREEE_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+		TREEE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+		TREEE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+	}
+	TREEE_HIP(hipEventRecord(ev_fork, stream));
+	TREEE_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+	return TREEE_OK;
+}
+void treee_ctx::on_aux(bool yes) {
+	if (yes && aux && stream != aux) {
+		main_stream = stream;
+		stream = aux;
+	} else if (!yes && aux && stream == aux) {
+		stream = main_stream;
+	}
+}
+int32_t treee_ctx::join() {
+	on_aux(false);
+	if (!aux) return TREEE_OK;
+	TREEE_HIP(hipEventRecord(ev_join, aux));
+	TREEE_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+	return TREEE_OK;
+}
 
 int32_t treee_ctx::reset() {
 	// coalesce into one block if the previous call had to chain several
@@ -261,6 +306,12 @@ int32_t treee_ctx_destroy(treee_ctx *ctx) {
 	}
 	for (auto &b : ctx->pool_idle) (void)hipFree(b.p);
 	for (auto &b : ctx->blocks) (void)hipFree(b.p);
+	if (ctx->aux) {
+		(void)hipStreamSynchronize(ctx->aux);
+		(void)hipStreamDestroy(ctx->aux);
+		(void)hipEventDestroy(ctx->ev_fork);
+		(void)hipEventDestroy(ctx->ev_join);
+	}
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
 	delete ctx;

@@ -158,7 +158,15 @@ __global__ __launch_bounds__(256) void k_oct_finish(treee_octree_node *__restric
 	}
 }
 
+int32_t build_octree_on(treee_ctx *ctx, treee_octree *o);
+// (the sorted cloud may belong to another context -- treee_octree_complete_dev on a second stream: HandleSync)
 int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
+	TREEE_TRY(use_begin(ctx, o->sc->owner, &o->sc->sync));
+	const int32_t rc = build_octree_on(ctx, o);
+	const int32_t e = use_end(ctx, o->sc->owner, &o->sc->sync);
+	return rc != TREEE_OK ? rc : e;
+}
+int32_t build_octree_on(treee_ctx *ctx, treee_octree *o) {
 	const uint64_t n = o->sc->n;
 	if (n == 0) return cube_to_host(ctx, o->sc.get());
 	hipStream_t st = ctx->stream;
@@ -242,14 +250,79 @@ int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, con
 	o->owner = ctx;
 	o->leaf_cap = leaf_cap ? leaf_cap : 256;
 	o->lod_cap = lod_cap ? lod_cap : 256;
-	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, corner, size, o->sc.get());
-	if (rc == TREEE_OK) rc = build_octree(ctx, o);
+	// the octree levels need the sorted keys only: they run on the context's auxiliary stream beside the gather of the
+	// sorted records (k_gather_sorted is a random 12-B gather, 0.33 ms per 15 M points; the levels are ~50 small dependent
+	// launches that leave the GPU idle).  Joined before returning.
+	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, corner, size, o->sc.get(), /*fork_after_sort=*/true);
+	if (rc == TREEE_OK) {
+		ctx->on_aux(true);
+		rc = build_octree(ctx, o);
+	}
+	const int32_t jr = ctx->join();
+	if (rc == TREEE_OK) rc = jr;
 	if (rc != TREEE_OK) {
 		treee_octree_free(o);
 		return rc;
 	}
 	*out = o;
 	return TREEE_OK;
+}
+
+int32_t treee_sort_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3], float size, treee_octree **out) {
+	if (!ctx || !out || (n && !d_xyz)) return set_err(TREEE_ERR_INVALID, "treee_sort_dev: null argument");
+	*out = nullptr;
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	treee_octree *o = new treee_octree;
+	o->device = ctx->device;
+	o->owner = ctx;
+	o->leaf_cap = o->lod_cap = 0; // no node table yet (treee_octree_complete_dev)
+	SortedCloud *sc = o->sc.get();
+	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, corner, size, sc);
+	// one round trip brings what a kNN structure over this cloud and the handle's info need on the host: the cube when it
+	// was computed from the data, and whether a Morton cell is crowded (refine_dense_cells) -- so neither asks again
+	if (rc == TREEE_OK && (sc->cube_pending || n > LONG_RUN)) {
+		uint32_t *h = ctx->h_scalars, *d_flag = nullptr;
+		float *h_cube = (float *)(h + 4);
+		rc = ctx->alloc_t(1, &d_flag);
+		if (rc == TREEE_OK) rc = long_run_flag_dev(ctx, sc->d_keys, n, d_flag);
+		if (rc == TREEE_OK && hipMemcpyAsync(h, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "flag copy");
+		if (rc == TREEE_OK) rc = cube_fetch_async(ctx, sc, h_cube);
+		if (rc == TREEE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_dev: synchronise");
+		if (rc == TREEE_OK) {
+			sc->crowded = (int)h[0];
+			cube_commit(sc, h_cube);
+		}
+	}
+	if (rc == TREEE_OK) rc = mark_ready(ctx, &sc->sync); // what a completion on another stream waits for
+	if (rc != TREEE_OK) {
+		treee_octree_free(o);
+		return rc;
+	}
+	*out = o;
+	return TREEE_OK;
+}
+
+int32_t treee_octree_complete_dev(treee_ctx *ctx, treee_octree *o, uint32_t leaf_cap, uint32_t lod_cap) {
+	if (!ctx || !o) return set_err(TREEE_ERR_INVALID, "treee_octree_complete_dev: null argument");
+	if (o->d_nodes || o->leaf_cap) return set_err(TREEE_ERR_INVALID, "treee_octree_complete_dev: the handle already has its node table");
+	if (ctx->device != o->device) return set_err(TREEE_ERR_INVALID, "treee_octree_complete_dev: context of another device");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	o->owner = ctx; // the node table, leaf ids and LOD lists come from (and return to) this context's pool
+	o->leaf_cap = leaf_cap ? leaf_cap : 256;
+	o->lod_cap = lod_cap ? lod_cap : 256;
+	const int32_t rc = build_octree(ctx, o);
+	if (rc != TREEE_OK) { // back to the sort-only state
+		pool_release(o->owner, o->d_nodes);
+		pool_release(o->owner, o->d_leaf);
+		pool_release(o->owner, o->d_lod);
+		o->d_nodes = nullptr;
+		o->d_leaf = o->d_lod = nullptr;
+		o->n_nodes = o->n_lod = 0;
+		o->leaf_cap = o->lod_cap = 0;
+	}
+	return rc;
 }
 
 int32_t treee_sort_build(const float *xyz, uint64_t n, const float corner[3], float size, uint32_t leaf_cap,

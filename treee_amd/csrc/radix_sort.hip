@@ -487,7 +487,7 @@ int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, ui
 	return TREEE_OK;
 }
 
-int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc) {
+int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc, bool fork_after_sort) {
 	sc->n = n;
 	sc->device = ctx->device;
 	sc->owner = ctx;
@@ -513,6 +513,9 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 		TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
 	}
 	TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, sc->d_keys, sc->d_perm));
+	// keys and permutation are final here: work that needs nothing else (the octree levels) may start on the context's
+	// auxiliary stream while this one gathers the records
+	if (fork_after_sort) TREEE_TRY(ctx->fork());
 	TREEE_TRY(gather_sorted_dev(ctx, d_xyz, sc->d_perm, n, sc->d_sorted));
 	return TREEE_OK;
 }
