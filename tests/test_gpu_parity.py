@@ -1356,3 +1356,29 @@ def test_deferred_octree_on_a_second_stream(T, oracle):
     ref_tree.close()
     ref.close()
     ctx_side.sync()
+
+
+def test_segments_dealt_to_ranks_give_the_same_calculations(T):
+    """SURVEY 8 E, first form, for the Calculations phase: segments are independent units (one rayon task each in the
+    reference, calculations.rs:97), so dealing them to N ranks and running treee_segments_calculate on every share gives
+    bit for bit what one GPU computes for all of them -- no exchange; an empty cloud and empty segments are legal inputs"""
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(150_000, plot=22.0)
+    seg = seg.astype(np.uint32)
+    S = int(seg.max()) + 1
+    whole = T.segments_calculate(pts, seg, S)
+    for world in (2, 3):
+        owner = D.partition_segments(np.bincount(seg, minlength=S), world)
+        for rank in range(world):
+            mine = owner[seg] == rank
+            local_ids = np.unique(seg[mine])
+            dense = np.searchsorted(local_ids, seg[mine]).astype(np.uint32)
+            part = T.segments_calculate(pts[mine], dense, len(local_ids))
+            for name in ("min", "max", "info"):
+                assert np.array_equal(getattr(part, name).view(np.uint32), getattr(whole, name)[local_ids].view(np.uint32)), name
+            for name in ("classification", "expansion", "height"):
+                assert np.array_equal(getattr(part, name).view(np.uint32), getattr(whole, name)[mine].view(np.uint32)), name
+    none = T.segments_calculate(np.zeros((0, 3), np.float32), np.zeros(0, np.uint32), 3)  # Calculations::new on empty Vecs
+    assert np.array_equal(none.min, np.zeros((3, 3), np.float32)) and np.array_equal(none.info, np.zeros((3, 4), np.float32)) and len(none.height) == 0
