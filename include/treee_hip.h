@@ -147,6 +147,21 @@ int32_t treee_curvature_segments(const float *xyz_aos, const uint32_t *segment, 
 /* map_to_u32 (treee/src/calculations.rs:455-457) over a device array */
 int32_t treee_map_to_u32_dev(treee_ctx *ctx, const float *d_in, uint64_t n, uint32_t *d_out);
 
+/* ---- F1: the slice segmentation that produces `segment: Vec<u32>` (host code, as in the reference) ---- */
+/* segmentation (treee/src/segmenting.rs:110-235) with TreeSet::new / add_point / filter_trees / tree_positions (:419-524),
+ * Tree (:242-396) and centroid (:526-545): 1 m height slices top-down, per slice the convex areas grown from its points,
+ * matched to the centroids handed down from the slice above, Voronoi cells of the centroids clipped to the box
+ * [bbox_min_xz, bbox_max_xz] (the loaded cloud's min / max in x and z), every point assigned to the first cell that
+ * contains it with 0.1 slack (move-to-front order).  segment_out[i] = id of point i, 0 = none (DELETED_INDEX);
+ * *n_segments_out = largest id + 1.  The reference's run is random (thread_rng shuffle, RandomState map order, random
+ * ids) and its Voronoi cells come from a third-party crate absent from the snapshot: this is the deterministic variant
+ * SURVEY.md F1 prescribes -- seeded shuffle, ordered maps, ids 1, 2, 3 ... in creation order, cells restated -- with
+ * every departure marked in csrc/segmenting.hip.  It runs on the host: the algorithm is serial per slice (each point
+ * is tested against the hulls the earlier points built), the reference keeps it on CPU workers too.
+ * max_distance: the reference's slider value (default 0.75, segmenting.rs:16). */
+int32_t treee_segment_slices(const float *xyz_aos, uint64_t n, const float bbox_min_xz[2], const float bbox_max_xz[2],
+                             float max_distance, uint64_t seed, uint32_t *segment_out, uint32_t *n_segments_out);
+
 /* ---- F4: the Calculations phase around the kNN consumer, all segments in one call ------ */
 /* SegmentData::new for every segment of a segmented cloud (treee/src/calculations.rs:133-175, run per segment by
  * Calculations::new :97-118): seg_min / seg_max [n_segments][3]; SegmentInformation::new (:210-276) ->

@@ -9,6 +9,7 @@
 //   k_nearest::Entry<f32>                                                                   k-nearest/src/kd_tree.rs:8-12
 //   NeighborsTree::{new, get}                                                               treee/src/calculations.rs:392-419
 //   the `curve` branch of SegmentInformation::update, map_to_u32                             treee/src/calculations.rs:328-373,455-457
+//   segmentation (slices -> segment ids; deterministic variant)                               treee/src/segmenting.rs:110-235
 //   SegmentData::new, SegmentInformation::{new, update}, Classification (all segments at once) treee/src/calculations.rs:133-327
 //   render::PointCloud::render into a depth + id buffer, PointCloudEnvironment              render/src/point_cloud.rs:148-173,206-243
 //   Camera3D projection                                                                     render/src/camera_3d.rs:16-18
@@ -141,6 +142,24 @@ inline std::vector<float> curvature_segments(const std::vector<Point3> &data, co
 		check(treee_curvature_segments(data[0].data(), segment.data(), data.size(), n_segments, neighbors_count, neighbors_max_distance, curve.data()));
 	return curve;
 }
+// ---- the Segmenting phase (segmenting.rs:110-235): the `segment: Vec<u32>` of Event::PointCloud (program.rs:18-22) ----
+constexpr float DEFAULT_MAX_DISTANCE = 0.75f; // segmenting.rs:16
+constexpr uint32_t DELETED_INDEX = 0;         // interactive/mod.rs:19
+struct Segmentation {
+	std::vector<uint32_t> segment; // id of every point, DELETED_INDEX = in no cell
+	uint32_t n_segments = 1;       // largest id + 1
+};
+// `min` / `max`: the loaded cloud's bounds as Loading keeps them (loading.rs:16-17); only x and z are used (:148-154).
+// Deterministic variant of the reference's random run (seeded shuffle, ordered maps, ids in creation order): treee_hip.h
+inline Segmentation segmentation(const std::vector<Point3> &points, const Point3 &min, const Point3 &max, float max_distance = DEFAULT_MAX_DISTANCE,
+                                 uint64_t seed = 0) {
+	Segmentation r;
+	r.segment.resize(points.size());
+	const float bmin[2] = {min[0], min[2]}, bmax[2] = {max[0], max[2]};
+	check(treee_segment_slices(points.empty() ? nullptr : points[0].data(), points.size(), bmin, bmax, max_distance, seed, r.segment.data(), &r.n_segments));
+	return r;
+}
+
 // ---- the Calculations phase (calculations.rs:97-118): what `Shared.segments` holds afterwards, for all segments ----
 enum class Classification : uint32_t { Ground = 0, Trunk = 1, Crown = 2 }; // calculations.rs:45-58
 struct SegmentInformation {                                               // calculations.rs:190-197

@@ -174,6 +174,25 @@ int main() {
 		}
 		CHECK(threw);
 	}
+	// ---- segmentation (segmenting.rs:110-235): separate columns keep one id each through all slices -------------
+	{
+		std::vector<Point3> cols;
+		std::vector<uint32_t> truth;
+		const float cx[3] = {-9.0f, 0.0f, 9.0f}, cz[3] = {-7.0f, 8.0f, -6.0f};
+		for (uint32_t t = 0; t < 3; ++t)
+			for (int i = 0; i < 700; ++i) {
+				const float a = u01(seed) * 6.2831853f, r = 0.7f * std::sqrt(u01(seed));
+				cols.push_back({cx[t] + r * std::cos(a), u01(seed) * 5.5f, cz[t] + r * std::sin(a)});
+				truth.push_back(t);
+			}
+		const treee::Segmentation sg = treee::segmentation(cols, {-10.0f, 0.0f, -8.0f}, {10.0f, 5.5f, 9.0f});
+		CHECK(sg.n_segments == 4);
+		uint32_t id_of[3] = {sg.segment[0], sg.segment[700], sg.segment[1400]};
+		CHECK(id_of[0] != id_of[1] && id_of[1] != id_of[2] && id_of[0] != id_of[2] && id_of[0] >= 1 && id_of[0] <= 3);
+		size_t same = 0;
+		for (size_t i = 0; i < cols.size(); ++i) same += sg.segment[i] == id_of[truth[i]];
+		CHECK(same == cols.size());
+	}
 	// ---- PointCloud::render into depth + id (point_cloud.rs:148-173, point_cloud.wgsl) --------------------
 	{
 		const uint32_t w = 160, h = 90;

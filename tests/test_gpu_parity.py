@@ -1382,3 +1382,48 @@ def test_segments_dealt_to_ranks_give_the_same_calculations(T):
                 assert np.array_equal(getattr(part, name).view(np.uint32), getattr(whole, name)[mine].view(np.uint32)), name
     none = T.segments_calculate(np.zeros((0, 3), np.float32), np.zeros(0, np.uint32), 3)  # Calculations::new on empty Vecs
     assert np.array_equal(none.min, np.zeros((3, 3), np.float32)) and np.array_equal(none.info, np.zeros((3, 4), np.float32)) and len(none.height) == 0
+
+
+def test_load_segment_calculate_display_splat_end_to_end(T, oracle):
+    """the phases of the reference in their order on one small plot, every seam through the library: LAS records ->
+    Chunk::read (GPU) -> segmentation (host) -> Calculations (GPU) -> curvature per segment (GPU) -> DisplayData values (GPU)
+    -> splat (GPU); the pieces are checked against the oracle where one exists and for consistency where they meet"""
+    import torch
+
+    from treee_amd import synth
+    from treee_amd.laz import Laz
+
+    rng = np.random.default_rng(3)
+    cols = [(-6.0, -5.0), (5.0, -6.0), (0.0, 6.0)]
+    parts = []
+    for cx, cz in cols:  # a trunk under a crown
+        n = 2500
+        h = rng.uniform(0, 9, n)
+        r = np.where(h > 4, 1.6, 0.15) * np.sqrt(rng.uniform(0, 1, n))
+        a = rng.uniform(0, 2 * np.pi, n)
+        parts.append(np.stack([cx + r * np.cos(a), h, cz + r * np.sin(a)], 1))
+    world = np.concatenate(parts)
+    ints = np.round(np.stack([world[:, 0], -world[:, 2], world[:, 1]], 1) / 0.001).astype(np.int32)  # LAS axes (laz.rs:210)
+    laz = Laz(synth.las_bytes(ints, scale=(0.001,) * 3))
+    chunks = []
+    laz.read(lambda c: chunks.append(c.read()))
+    pts = np.concatenate(chunks)
+    assert np.array_equal(pts, oracle.decode_las_records(laz.data[laz.header.offset_to_point_data:], len(pts), laz.point_length, laz.scale, laz.offset, laz.center))
+    seg, S = T.segment_slices(pts, laz.min, laz.max)
+    assert S == 4 and all(len(np.unique(seg[i * 2500:(i + 1) * 2500])) == 1 for i in range(3))
+    d_pts, d_seg = torch.from_numpy(pts).cuda(), torch.from_numpy(seg.astype(np.int32)).cuda()
+    calc = T.segments_calculate(d_pts, d_seg, S)
+    curve = T.curvature_segments(d_pts, d_seg, S)
+    vals = T.display_values_dev(d_seg, S, calc.classification, curve, calc.expansion, calc.height)
+    torch.cuda.synchronize()
+    info = calc.info.cpu().numpy()
+    assert np.all(np.abs(info[1:, 0] - 4.0) < 0.3) and np.all(np.abs(info[1:, 1] - 5.0) < 0.3)  # trunk 4 m, crown 5 m
+    cls = calc.classification.cpu().numpy()
+    assert (cls[pts[:, 1] - pts[:, 1].min() > 4.3] == 2).all() and (cls[pts[:, 1] - pts[:, 1].min() < 3.7] < 2).all()
+    w, h = 192, 108
+    view = T.view_from_transform(T.translation(0.0, 4.0, 30.0))
+    depth, ids = T.PointCloud(d_pts).render(T.PointCloudProperty(vals["classification"]), view, T.Camera3D(w / h).projection(),
+                                            T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1), w, h)
+    rd, ri, _ = oracle.splat(pts, vals["classification"].cpu().numpy().view(np.uint32), view, T.Camera3D(w / h).projection(), 0.1, 0, 0xFFFFFFFF, w, h)
+    assert np.array_equal(depth.cpu().numpy().view(np.uint32), rd.view(np.uint32)) and np.array_equal(ids.cpu().numpy().view(np.uint32), ri)
+    assert {0xFFFFFFFF // 8 * 3, 0xFFFFFFFF // 8 * 6} <= set(np.unique(ri))  # trunks and crowns are on screen

@@ -28,5 +28,6 @@ from .render import (  # noqa: F401
 )
 from .laz import Chunk, CorruptFile, Header, Laz, slice_bin, slice_keys  # noqa: F401
 from .export import rust_display_f32, save_points, segment_save  # noqa: F401
+from .segmenting import segment_slices  # noqa: F401
 
 __version__ = "0.1.0"

@@ -84,6 +84,7 @@ SYMBOLS = {
     "treee_slice_bin": (_i32, [_vp, _u64, C.POINTER(C.c_int64), C.POINTER(_u64), _vp, _vp, _u64]),
     "treee_slice_bin_dev": (_i32, [_vp, _vp, _u64, C.POINTER(C.c_int64), C.POINTER(_u64), _vp, _vp, _u64]),
     "treee_select_xz_dev": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+    "treee_segment_slices": (_i32, [_vp, _u64, _vp, _vp, _f32, _u64, _vp, C.POINTER(_u32)]),
     "treee_segments_calculate": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "treee_segments_calculate_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "treee_display_values_dev": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
