@@ -262,6 +262,7 @@ def main():
             out["ingest"] = ingest_stage(n, dev, ctx)
             out["per_segment_knn"] = segment_stage(pts, seg, ctx)
             out["calculations"] = calculations_stage(pts, seg, ctx, cpu=not args.no_cpu_baseline)
+            out["segmentation_host"] = segmentation_stage()
             out["eye_dome"] = eye_dome_stage(depth, ctx)
             out["out_of_core"] = out_of_core_stage(dev, n, proj)
         if world == 1 and not args.no_cpu_baseline:
@@ -384,6 +385,23 @@ def segment_stage(pts, seg, ctx):
         "knn_curve_ms": round(res["curve"], 3),
         "Mpoints_per_s": round(n / ((res["build"] + res["curve"]) * 1e-3) / 1e6, 1),
     }
+
+
+def segmentation_stage(sample=1_500_000):
+    """SURVEY 8 F1, beside the step: the Segmenting phase (segmenting.rs:110-235) is host code in the reference and in the
+    library (serial per slice; slices over a thread pool).  Timed on a forest patch of the step's density."""
+    import treee_amd as T
+    from treee_amd import synth
+
+    plot = PLOT * (sample / 15_000_000) ** 0.5
+    p, _ = synth.forest_cloud_torch(sample, "cuda", plot=plot)
+    host = p.cpu().numpy()
+    t0 = time.perf_counter()
+    sg, nseg = T.segment_slices(host, seed=1)
+    dt = time.perf_counter() - t0
+    return {"workload": f"{sample}-point forest patch ({plot:.0f} m), max_distance 0.75: slices -> hulls -> centroid hand-off -> Voronoi cells -> ids",
+            "seconds": round(dt, 3), "Mpoints_per_s": round(sample / dt / 1e6, 3), "segments": int(nseg) - 1, "host_threads": os.cpu_count(),
+            "assigned_fraction": round(float((sg > 0).mean()), 4)}
 
 
 def calculations_stage(pts, seg, ctx, cpu=True):

@@ -15,15 +15,18 @@
 //       middle of each side, every cell clipped to the box -- computed here as the intersection of the box with the
 //       bisector half-planes of all other sites (the same polygons; vertex order starts at the box's min corner, counter-
 //       clockwise), in f64 and stored as f32 like `Centroid::from_xy` (:410-412).  Parity with the crate: unpinned.
-// The slices themselves are sequential here (the reference pipelines them over rayon workers, the hand-off chain is the
-// same).  The work is inherently serial per slice -- every point is tested against the hulls the earlier points built --
+// Slices run on a thread pool as the reference's run on rayon workers, the centroid hand-off chain between them is
+// sequential in both; the result does not depend on the number of threads.  The work is inherently serial per slice -- every point is tested against the hulls the earlier points built --
 // which is why the reference keeps it on the CPU and so does this library: there is no GPU path to fall back from.
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <deque>
+#include <functional>
 #include <map>
+#include <thread>
 
 using namespace treee;
 
@@ -304,31 +307,60 @@ int32_t treee_segment_slices(const float *xyz, uint64_t n, const float bbox_min_
 		const int64_t key = !(f == f) ? 0 : (f >= 9.2233720368547758e18f ? INT64_MAX : (f <= -9.2233720368547758e18f ? INT64_MIN : (int64_t)f)); // `as isize`
 		slices[key].push_back((uint32_t)i);
 	}
-	std::map<uint32_t, P2> centroids; // handed from a slice to the one below it (:135-146, 173-179)
+	// The reference gives every slice to a rayon worker (:164-234): TreeSet::new needs nothing from the other slices, the
+	// centroids travel down a chain of channels (:135-146, :173-179), and the cells and the assignment of a slice need only
+	// its own centroid map.  Same three stages here -- the outer two over a thread pool, the chain sequential -- and the
+	// same result whatever the number of threads.
 	uint32_t next_id = 1;
 	if (!slices.empty()) {
 		const int64_t lo = slices.begin()->first, hi = slices.rbegin()->first;
-		for (int64_t key = hi;; --key) { // top-down; a layer without points still hands the centroids on (:141)
-			static const std::vector<uint32_t> none;
+		const size_t layers = (size_t)(hi - lo + 1); // a layer without points still hands the centroids on (:141)
+		struct Layer {
+			std::vector<uint32_t> order;
+			TreeSet set;
+			std::map<uint32_t, P2> centroids;
+		};
+		std::vector<Layer> layer(layers); // layer[0] = top slice
+		auto parallel_for = [&](const std::function<void(size_t)> &fn) {
+			unsigned workers = std::thread::hardware_concurrency();
+			if (workers == 0) workers = 1;
+			if (workers > layers) workers = (unsigned)layers;
+			std::atomic<size_t> next{0};
+			std::vector<std::thread> pool;
+			for (unsigned w = 0; w + 1 < workers; ++w)
+				pool.emplace_back([&] {
+					for (size_t i; (i = next.fetch_add(1)) < layers;) fn(i);
+				});
+			for (size_t i; (i = next.fetch_add(1)) < layers;) fn(i);
+			for (auto &t : pool) t.join();
+		};
+		parallel_for([&](size_t li) { // shuffle (D1) + TreeSet::new (:423-435)
+			const int64_t key = hi - (int64_t)li;
 			auto it = slices.find(key);
-			std::vector<uint32_t> order = it == slices.end() ? none : it->second;
-			// D1: points.shuffle(..) -> Fisher-Yates from the end, SplitMix64 keyed by (seed, slice key)
+			if (it != slices.end()) layer[li].order = it->second;
+			std::vector<uint32_t> &order = layer[li].order;
 			SplitMix64 rng{seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(key - lo + 1))};
 			for (size_t i = order.size(); i > 1; --i) std::swap(order[i - 1], order[(size_t)(rng.next() % i)]);
-			TreeSet set; // TreeSet::new (:423-435)
-			for (const uint32_t p : order) set.add_point({xyz[3ull * p + 0], xyz[3ull * p + 2]}, max_distance);
-			set.filter_trees(max_distance);
-			centroids = set.tree_positions(centroids, max_distance, &next_id);
+			for (const uint32_t p : order) layer[li].set.add_point({xyz[3ull * p + 0], xyz[3ull * p + 2]}, max_distance);
+			layer[li].set.filter_trees(max_distance);
+		});
+		std::map<uint32_t, P2> centroids; // handed from a slice to the one below it
+		for (size_t li = 0; li < layers; ++li) {
+			centroids = layer[li].set.tree_positions(centroids, max_distance, &next_id);
+			layer[li].centroids = centroids;
+		}
+		parallel_for([&](size_t li) { // cells (D4) + assignment (:181-203)
 			std::vector<uint32_t> ids;
 			std::vector<P2> sites;
-			for (const auto &kv : centroids) { // D2
+			for (const auto &kv : layer[li].centroids) { // D2
 				ids.push_back(kv.first);
 				sites.push_back(kv.second);
 			}
+			if (layer[li].order.empty()) return; // (no point to assign: the cells would not be looked at)
 			const std::vector<std::vector<P2>> cells = voronoi_cells(bmin, bmax, sites);
 			std::deque<std::pair<Tree, uint32_t>> trees;
 			for (size_t c = 0; c < cells.size(); ++c) trees.emplace_back(Tree::from_points(cells[c]), ids[c]);
-			for (const uint32_t p : order) { // :189-203: first cell that contains the point (0.1 slack), moved to the front
+			for (const uint32_t p : layer[li].order) { // first cell that contains the point (0.1 slack), moved to the front
 				const P2 q = {xyz[3ull * p + 0], xyz[3ull * p + 2]};
 				size_t at = trees.size();
 				for (size_t c = 0; c < trees.size(); ++c)
@@ -345,8 +377,7 @@ int32_t treee_segment_slices(const float *xyz, uint64_t n, const float bbox_min_
 				segment_out[p] = elem.second;
 				trees.push_front(std::move(elem));
 			}
-			if (key == lo) break;
-		}
+		});
 	}
 	if (n_segments_out) *n_segments_out = next_id;
 	return TREEE_OK;
