@@ -104,7 +104,8 @@ int32_t treee_knn_len(const treee_knn *t, uint64_t *n_out);
  * number of valid entries; out[i*k .. i*k+counts[i]) ascending by distance, all distance <
  * max_dist_sq (strict, squared).  Tie rule: distances and counts are
  * bit-identical to the reference; among equal distances the entry with the smaller
- * (morton key, index) wins.  k == 0 -> TREEE_ERR_INVALID (reference panics).
+ * (cell key, index) wins -- the key is the 30-bit Hilbert index of the point's cell in the
+ * structure's cube (the order of the structure's buckets).  k == 0 -> TREEE_ERR_INVALID (reference panics).
  * k <= 16, <= 32 and <= 64 run register-resident lists of that length (the reference uses 31);
  * 64 < k <= 319 runs an LDS-heap kernel; larger k -> TREEE_ERR_UNSUPPORTED. */
 int32_t treee_knn_query_batch(const treee_knn *t, const float *q_xyz, uint64_t nq, uint32_t k,

@@ -54,6 +54,37 @@ void orc_morton_keys(const float *xyz, uint64_t n, const float corner[3], float 
 	}
 }
 
+// 30-bit Hilbert index of the same three 10-bit cell coordinates (J. Skilling, "Programming the Hilbert curve", AIP Conf.
+// Proc. 707, 2004: AxesToTranspose, then the transposed bits read most significant first).  BUILD-DEFINED like the Morton
+// key: the kNN structure orders its buckets by it, and the library's tie rule is (distance, this key, original index).
+void orc_hilbert_keys(const float *xyz, uint64_t n, const float corner[3], float size, uint32_t *keys_out) {
+	for (uint64_t i = 0; i < n; ++i) {
+		uint32_t X[3] = {quant(xyz[3 * i + 0], corner[0], size), quant(xyz[3 * i + 1], corner[1], size), quant(xyz[3 * i + 2], corner[2], size)};
+		const uint32_t M = 1u << 9;
+		for (uint32_t Q = M; Q > 1; Q >>= 1) { // inverse undo
+			const uint32_t P = Q - 1;
+			for (int a = 0; a < 3; ++a) {
+				if (X[a] & Q) {
+					X[0] ^= P; // invert
+				} else { // exchange
+					const uint32_t t = (X[0] ^ X[a]) & P;
+					X[0] ^= t;
+					X[a] ^= t;
+				}
+			}
+		}
+		for (int a = 1; a < 3; ++a) X[a] ^= X[a - 1]; // Gray encode
+		uint32_t t = 0;
+		for (uint32_t Q = M; Q > 1; Q >>= 1)
+			if (X[2] & Q) t ^= Q - 1;
+		for (int a = 0; a < 3; ++a) X[a] ^= t;
+		uint32_t h = 0;
+		for (int b = 9; b >= 0; --b)
+			for (int a = 0; a < 3; ++a) h = (h << 1) | ((X[a] >> b) & 1u);
+		keys_out[i] = h;
+	}
+}
+
 void orc_sort_keys(const uint32_t *keys, uint64_t n, uint32_t *sorted_keys_out, uint32_t *perm_out) {
 	std::vector<uint32_t> perm(n);
 	std::iota(perm.begin(), perm.end(), 0u);

@@ -86,6 +86,7 @@ def lib():
         L.orc_splat.argtypes = [vp, vp, u64, vp, vp, f32, u32, u32, u32, u32, vp, vp, vp]
         L.orc_eye_dome.argtypes = [vp, u32, u32, f32, vp]
         L.orc_morton_keys.argtypes = [vp, u64, vp, f32, vp]
+        L.orc_hilbert_keys.argtypes = [vp, u64, vp, f32, vp]
         L.orc_sort_keys.argtypes = [vp, u64, vp, vp]
         L.orc_octree_build.restype = u64
         L.orc_octree_build.argtypes = [vp, u64, u32, u32, vp, u64, vp, vp, u64, vp]
@@ -258,6 +259,14 @@ def morton_keys(points, corner, size):
     corner = _f32(corner).reshape(3)
     out = np.zeros(len(points), np.uint32)
     lib().orc_morton_keys(_p(points), len(points), _p(corner), size, _p(out))
+    return out
+
+
+def hilbert_keys(points, corner, size):
+    points = _f32(points, 3)
+    corner = _f32(corner).reshape(3)
+    out = np.zeros(len(points), np.uint32)
+    lib().orc_hilbert_keys(_p(points), len(points), _p(corner), size, _p(out))
     return out
 
 

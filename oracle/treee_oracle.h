@@ -141,6 +141,10 @@ typedef struct {
 
 void orc_morton_keys(const float *xyz, uint64_t n, const float corner[3], float size,
                      uint32_t *keys_out);
+/* Hilbert index (Skilling 2004) of the same 10-bit cell coordinates: the order of the kNN structure's buckets and the
+ * middle term of the library's tie rule (distance, key, original index) */
+void orc_hilbert_keys(const float *xyz, uint64_t n, const float corner[3], float size,
+                      uint32_t *keys_out);
 /* stable sort by key: perm_out[i] = original index of sorted position i */
 void orc_sort_keys(const uint32_t *keys, uint64_t n, uint32_t *sorted_keys_out, uint32_t *perm_out);
 /* nodes in BFS order; returns node count (call with nodes==NULL to size).

@@ -145,9 +145,9 @@ def test_knn_external_queries_and_ties(T, oracle):
     g_ent, g_cnt = tree.k_nearest_batch(q, 31, F32_MAX)
     ndiff = check_knn_contract(pts, q, g_ent, g_cnt, r_ent, r_cnt)
     assert ndiff > 0  # the tie rule really differs from KD-tree visit order on a lattice
-    # canonical order (distance, morton key, index): bit-exact incl. indices
+    # canonical order (distance, Hilbert key of the cell, index): bit-exact incl. indices
     corner, size = cube_of(pts)
-    keys = oracle.morton_keys(pts, corner, size).astype(np.uint64)
+    keys = oracle.hilbert_keys(pts, corner, size).astype(np.uint64)
     for i in range(0, len(q), 17):
         d = f32_dist_sq(pts, q[i]).view(np.uint32).astype(np.uint64)
         order = np.lexsort((np.arange(len(pts)), keys, d))[:31]
@@ -812,7 +812,7 @@ def test_knn_heap_and_sorted_kernels_agree(T):
     import sys
 
     # the general-k heap kernel (forced through the env hook in a child process) must give the
-    # same bits as the sorted-32 kernel: both implement the total order (distance, morton key, index)
+    # same bits as the sorted-32 kernel: both implement the total order (distance, cell key, index)
     code = ("import numpy as np, treee_amd as T\n"
             "rng=np.random.default_rng(3); p=(np.round(rng.random((20000,3))*np.array([30,8,30])*100)/100).astype(np.float32)\n"
             "e,c=T.KDTree.new(p).k_nearest_batch(p[:4000],31,float(np.finfo(np.float32).max))\n"
@@ -1077,8 +1077,13 @@ def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path, backend):
     whole = torch.cat([r["pts"] for r in res]).cuda()
     tree = T.KDTree.new(whole)
     d, _, c = tree.self_neighbors_dev(31)
+    d32, _, _ = tree.self_neighbors_dev(32)
     curve = tree.curvature_dev(31)
     torch.cuda.synchronize()
+    # a query whose 31st and 32nd neighbours are equally far may keep either (the tie rule's key depends on the cube, and the
+    # shard's cube is not the whole cloud's): its distances agree, its covariance need not.  A handful in 100 000 at most.
+    tied = (d32[:, 30] == d32[:, 31]).cpu().numpy()
+    assert tied.sum() <= 8
     o = 0
     for r in res:
         n = r["pts"].shape[0]
@@ -1087,7 +1092,9 @@ def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path, backend):
         assert torch.equal(r["count"], c[o : o + n].cpu())
         a, b = r["curve"].numpy(), curve[o : o + n].cpu().numpy()
         both = ~np.isnan(b)
-        assert np.array_equal(np.isnan(a), ~both) and np.max(np.abs(a[both] - b[both])) < 1e-4
+        assert np.array_equal(np.isnan(a), ~both)
+        both &= ~tied[o : o + n]
+        assert np.max(np.abs(a[both] - b[both])) < 1e-4
         o += n
     # the reduced frame is the frame one GPU draws of the whole cloud (global index = rank * n + local index)
     w, h = 240, 135

@@ -305,3 +305,25 @@ def test_display_values_constants(oracle):
                            np.array([-1.0, np.nan, 1.0], np.float32))
     assert out[0].tolist() == [0xFFFFFFFF // 8, 0xFFFFFFFF // 8 * 3, 0xFFFFFFFF // 8 * 6]
     assert out[1].tolist() == [0, 1 << 31, 0xFFFFFFFF] and out[2].tolist() == [1 << 30, 1 << 31, 0xFFFFFFFF] and out[3].tolist() == [0, 0, 0xFFFFFFFF]
+
+
+def test_hilbert_keys_are_a_curve_through_the_cells(oracle):
+    """the Hilbert index used by the kNN structure (Skilling 2004): a bijection of the 2^30 cells that, unlike the Morton key,
+    always steps to a face neighbour; and a prefix code of the octree -- the points of a level-l cell share the top 3 l bits"""
+    g = np.arange(8, dtype=np.float32)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3) + np.float32(0.5)  # the 512 cells of an 8^3 corner ...
+    keys = oracle.hilbert_keys(pts * np.float32(128.0), [0, 0, 0], 1024.0)  # ... scaled to 128-cell blocks: top 9 bits
+    top = keys >> 21
+    assert len(np.unique(top)) == 512
+    order = np.argsort(top)
+    steps = np.abs(np.diff(pts[order], axis=0)).sum(1)
+    assert np.all(steps == 1.0)  # consecutive cells share a face
+    mk = oracle.morton_keys(pts * np.float32(128.0), [0, 0, 0], 1024.0) >> 21
+    assert np.abs(np.diff(pts[np.argsort(mk)], axis=0)).sum(1).max() > 1.0  # the Z curve jumps
+    rng = np.random.default_rng(0)
+    p = (rng.random((20000, 3)) * 1024).astype(np.float32)
+    h, m = oracle.hilbert_keys(p, [0, 0, 0], 1024.0), oracle.morton_keys(p, [0, 0, 0], 1024.0)
+    for level in (1, 2, 3, 5):
+        sh = 30 - 3 * level
+        # same partition into level cells
+        assert len(np.unique(np.stack([h >> sh, m >> sh], 1), axis=0)) == len(np.unique(h >> sh)) == len(np.unique(m >> sh))

@@ -41,6 +41,47 @@ inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) /
 // ---- device helpers --------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// 30-bit Hilbert index of three 10-bit cell coordinates (Skilling's "transpose" form: J. Skilling, Programming the Hilbert
+// curve, AIP Conf. Proc. 707, 2004).  Like the Morton key it is a prefix code of the octree cells -- the top 3 l bits name
+// the level-l cell -- but consecutive indices are always face neighbours, so a run of consecutive points of the sorted order
+// is one spatially contiguous blob.  The kNN structure orders its buckets by it (knn.hip); the octree keeps Morton.
+__device__ __host__ inline uint32_t hilbert30(uint32_t x0, uint32_t x1, uint32_t x2) {
+	uint32_t X[3] = {x0, x1, x2};
+	for (uint32_t Q = 512u; Q > 1u; Q >>= 1) {
+		const uint32_t P = Q - 1u;
+		for (int i = 0; i < 3; ++i) {
+			if (X[i] & Q)
+				X[0] ^= P;
+			else {
+				const uint32_t t = (X[0] ^ X[i]) & P;
+				X[0] ^= t;
+				X[i] ^= t;
+			}
+		}
+	}
+	X[1] ^= X[0];
+	X[2] ^= X[1];
+	uint32_t t = 0;
+	for (uint32_t Q = 512u; Q > 1u; Q >>= 1)
+		if (X[2] & Q) t ^= Q - 1u;
+	X[0] ^= t;
+	X[1] ^= t;
+	X[2] ^= t;
+	uint32_t h = 0; // transpose -> index: bit b of X[0] is the most significant of the b-th triple
+	for (int b = 9; b >= 0; --b) h = (h << 3) | (((X[0] >> b) & 1u) << 2) | (((X[1] >> b) & 1u) << 1) | ((X[2] >> b) & 1u);
+	return h;
+}
+// every third bit of a 30-bit Morton key -> 10 bits (inverse of the key's spread)
+__device__ __host__ inline uint32_t compact3(uint32_t v) {
+	v &= 0x09249249u;
+	v = (v | (v >> 2)) & 0x030C30C3u;
+	v = (v | (v >> 4)) & 0x0300F00Fu;
+	v = (v | (v >> 8)) & 0x030000FFu;
+	v = (v | (v >> 16)) & 0x000003FFu;
+	return v;
+}
+__device__ __host__ inline uint32_t hilbert_of_morton(uint32_t key) { return hilbert30(compact3(key), compact3(key >> 1), compact3(key >> 2)); }
+
 // inclusive wave scan (64 lanes) of u32
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 	const int lane = lane_id();
@@ -184,6 +225,7 @@ struct SortedCloud {
 	uint32_t *d_perm = nullptr;  // sorted position -> original index
 	float4 *d_sorted = nullptr;  // (x,y,z,bitcast(orig)) sorted
 	int device = 0;
+	bool hilbert = false; // d_keys are Hilbert indices (the kNN structure's private copy), not Morton keys
 	int crowded = -1; // some Morton cell holds more than LONG_RUN points: -1 unknown, else 0 / 1 (long_run_flag_dev)
 	float *d_cube = nullptr;   // (corner.xyz, size) on the device when the cube was computed from the data
 	bool cube_pending = false; // corner / size above are not yet valid on the host (cube_fetch_async + cube_commit)
