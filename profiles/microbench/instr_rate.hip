@@ -52,6 +52,8 @@ template <int T> __global__ __launch_bounds__(1024) void k_rate(unsigned long lo
 	for (int i = threadIdx.x; i < 2048; i += blockDim.x) lds[i] = (float)i;
 	__syncthreads();
 	unsigned ofs = lane * 4 + (threadIdx.x >> 6) * 512;
+	unsigned ofs8 = (ofs * 2u) & 0x1FF8u, tmpv = 0u, c256 = 256u;
+	asm volatile("" : "+v"(ofs8), "+v"(tmpv), "+v"(c256));
 	unsigned long long cond = __ballot(f[0] > 20.0f);
 	unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #pragma unroll 1
@@ -102,6 +104,33 @@ template <int T> __global__ __launch_bounds__(1024) void k_rate(unsigned long lo
 #undef X
 		} else if constexpr (T == 11) {
 #define X(i) asm volatile("ds_write_b32 %0, %1" : : "v"(ofs), "v"(u[i]) : "memory");
+			TRIP(X)
+#undef X
+		} else if constexpr (T == 70) { // one 8-byte store per lane, lane stride 8 (an interleaved (position, distance) entry)
+#define X(i) asm volatile("ds_write_b64 %0, %1" : : "v"(ofs8), "v"(d[i]) : "memory");
+			TRIP(X)
+#undef X
+		} else if constexpr (T == 71) { // per-lane 8-byte read, lane stride 8
+#define X(i) asm volatile("ds_read_b64 %0, %1" : "=v"(d[i]) : "v"(ofs8) : "memory");
+			TRIP(X)
+#undef X
+			asm volatile("s_waitcnt lgkmcnt(0)");
+		} else if constexpr (T == 72) { // per-lane two-address read (the flush's read of one buffer slot today)
+#define X(i) asm volatile("ds_read2st64_b32 %0, %1 offset1:16" : "=v"(d[i]) : "v"(ofs) : "memory");
+			TRIP(X)
+#undef X
+			asm volatile("s_waitcnt lgkmcnt(0)");
+		} else if constexpr (T == 73) { // per-lane 4-byte read, lane stride 4
+#define X(i) asm volatile("ds_read_b32 %0, %1" : "=v"(u[i]) : "v"(ofs) : "memory");
+			TRIP(X)
+#undef X
+			asm volatile("s_waitcnt lgkmcnt(0)");
+		} else if constexpr (T == 74) { // v_cmpx + add under the new exec + exec restore: the conditional advance of the append
+#define X(i) asm volatile("v_cmpx_le_u32 %1, %2\n\tv_add_u32 %0, 0x100, %0\n\ts_mov_b64 exec, -1" : "+v"(u[i]) : "v"(w[i]), "v"(w[(i + 1) & 7]));
+			TRIP(X)
+#undef X
+		} else if constexpr (T == 75) { // the same advance as compare + select + add
+#define X(i) asm volatile("v_cmp_le_u32 vcc, %1, %2\n\tv_cndmask_b32 %3, 0, %4, vcc\n\tv_add_u32 %0, %3, %0" : "+v"(u[i]) : "v"(w[i]), "v"(w[(i + 1) & 7]), "v"(tmpv), "v"(c256) : "vcc");
 			TRIP(X)
 #undef X
 		} else if constexpr (T == 12) { // broadcast read, 8 bytes
@@ -385,6 +414,12 @@ int main() {
 	run<63>("ds_write2st64_b32 exec=every 4th lane", d_out);
 	run<64>("ds_write2st64_b32 exec=every 16th lane", d_out);
 	run<65>("ds_write2st64_b32 exec=0", d_out);
+	run<70>("ds_write_b64 (lane stride 8)", d_out);
+	run<71>("ds_read_b64 (lane stride 8)", d_out);
+	run<72>("ds_read2st64_b32 (per lane)", d_out);
+	run<73>("ds_read_b32 (per lane)", d_out);
+	run<74>("v_cmpx + v_add + s_mov exec (3 instr)", d_out, 3);
+	run<75>("v_cmp + v_cndmask + v_add (3 instr)", d_out, 3);
 	run<10>("ds_write2st64_b32", d_out);
 	run<11>("ds_write_b32", d_out);
 	run<12>("ds_read_b64 (broadcast)", d_out);
