@@ -327,3 +327,22 @@ def test_hilbert_keys_are_a_curve_through_the_cells(oracle):
         sh = 30 - 3 * level
         # same partition into level cells
         assert len(np.unique(np.stack([h >> sh, m >> sh], 1), axis=0)) == len(np.unique(h >> sh)) == len(np.unique(m >> sh))
+
+
+def test_library_hilbert_index_equals_the_oracles(oracle):
+    """the library's own hilbert30 / hilbert_of_morton (treee_amd/csrc/common.h -- one source for host and device), compiled
+    for the host, against the oracle's independent statement of Skilling's algorithm: 4 096 grid cells + 20 000 random cells"""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as G
+
+    exe = G.build_hilbert_host_test()
+    rows = np.array([[int(v) for v in line.split()] for line in subprocess.check_output([exe], text=True).splitlines()], dtype=np.int64)
+    assert rows.shape == (4096 + 20000, 5)
+    pts = rows[:, :3].astype(np.float32) + np.float32(0.5)  # the centre of cell (x, y, z) of the 1024^3 grid
+    want = oracle.hilbert_keys(pts, [0, 0, 0], 1024.0).astype(np.int64)
+    assert np.array_equal(rows[:, 3], want)  # from the three cell coordinates
+    assert np.array_equal(rows[:, 4], want)  # from the 30-bit Morton key
+    assert len(np.unique(rows[:4096, 3] >> 18)) == 4096  # (the 16^3 grid: one index prefix per level-4 cell)
