@@ -192,6 +192,8 @@ void retire(treee_ctx *owner, HandleSync *hs);
 // radix_sort.hip
 int32_t morton_keys_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3],
                         float size, uint32_t *d_keys);
+// Morton keys -> Hilbert indices of the same cells (hilbert_of_morton), optionally gathered through d_idx; d_out may be d_morton
+int32_t hilbert_keys_dev(treee_ctx *ctx, const uint32_t *d_morton, const uint32_t *d_idx, uint64_t n, uint32_t *d_out);
 // sorts (key,val) pairs by the low `bits` bits of key, stable.  d_vals_in == nullptr means
 // val = index.  Results land in d_keys_out / d_vals_out; tmp buffers come from the arena.
 int32_t sort_pairs_dev(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in,
@@ -239,8 +241,9 @@ struct SortedCloud {
 };
 // the sorted cloud of an octree can be shared with a kNN structure (one sort, two consumers)
 std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o);
+// hilbert_order: sort by the Hilbert index of the cell instead of its Morton key (a kNN structure's own cloud; out->hilbert)
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner,
-                           float size, SortedCloud *out, bool fork_after_sort = false);
+                           float size, SortedCloud *out, bool fork_after_sort = false, bool hilbert_order = false);
 // *d_flag (device, zeroed here) = 1 iff sorted keys hold a run of more than LONG_RUN equal keys
 #ifndef TREEE_LONG_RUN
 #define TREEE_LONG_RUN 256

@@ -1061,13 +1061,6 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 	}
 }
 
-// Morton keys -> Hilbert indices of the same cells (optionally gathered through `idx`)
-__global__ __launch_bounds__(256) void k_hilbert_keys(const uint32_t *__restrict__ morton, const uint32_t *__restrict__ idx, uint32_t n,
-                                                       uint32_t *__restrict__ out) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i < n) out[i] = hilbert_of_morton(morton[idx ? idx[i] : i]);
-}
-
 // start bucket of each query wave: the bucket holding the first query's key (the order of the tree: Hilbert, or Morton with TREEE_KNN_MORTON)
 __global__ __launch_bounds__(256) void k_query_start(const uint32_t *__restrict__ tree_keys, uint32_t n, uint32_t nb,
                                                       const uint32_t *__restrict__ q_keys_sorted, uint32_t nq,
@@ -1177,8 +1170,7 @@ int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint
 		TREEE_TRY(ctx->alloc_t(nwaves, &d_qs));
 		TREEE_TRY(morton_keys_dev(ctx, d_q, nq, t->sc->corner, t->sc->size, d_qk));
 		if (t->sc->hilbert) { // the tree is in Hilbert order: so are the queries (in place: one element per thread)
-			hipLaunchKernelGGL(k_hilbert_keys, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, d_qk, nullptr, (uint32_t)nq, d_qk);
-			TREEE_LAUNCH_CHECK();
+			TREEE_TRY(hilbert_keys_dev(ctx, d_qk, nullptr, nq, d_qk));
 		}
 		TREEE_TRY(sort_pairs_dev(ctx, d_qk, nullptr, nq, 30, d_qks, d_qo));
 		hipLaunchKernelGGL(k_query_start, dim3(div_up(nwaves, 256)), dim3(256), 0, ctx->stream, t->sc->d_keys, a.n, a.nb, d_qks, a.nq, nwaves, d_qs);
@@ -1326,6 +1318,8 @@ __global__ __launch_bounds__(256) void k_gather_rec(const float4 *__restrict__ s
 // their neighbourhoods -- 22.4 instead of 33.7 buckets scanned per wave, 8.7 instead of 11.5 ms per 15 M points; the second
 // sort costs ~0.6 ms.  Where a cell is crowded (> LONG_RUN points: see above) the copy is ordered by the 20-bit-per-axis
 // low bits inside the cell as before.  Results do not depend on the order (exact search); only the tie rule names it.
+// A cloud sorted for this structure alone (treee_knn_build_dev) is sorted by the Hilbert index in the first place
+// (build_sorted_cloud's hilbert_order: one sort), and comes through here only for the crowded-cell case.
 int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &sc, std::shared_ptr<SortedCloud> *out) {
 	*out = sc;
 	const uint64_t n = sc->n;
@@ -1349,13 +1343,13 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 		cube_commit(sc.get(), h_cube);
 	}
 	static const bool morton_order = getenv("TREEE_KNN_MORTON") != nullptr; // A/B hook: keep the shared Morton order
-	if (!flag && morton_order) return TREEE_OK;
+	if (!flag && (morton_order || sc->hilbert)) return TREEE_OK; // (a cloud sorted for this structure is in its order already)
 	auto fine = std::make_shared<SortedCloud>();
 	fine->n = n;
 	fine->device = sc->device;
 	fine->owner = ctx;
 	fine->size = sc->size;
-	fine->hilbert = !morton_order;
+	fine->hilbert = !morton_order || sc->hilbert;
 	for (int a = 0; a < 3; ++a) fine->corner[a] = sc->corner[a];
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_keys));
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_perm));
@@ -1374,11 +1368,12 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 		TREEE_TRY(sort_pairs_dev(ctx, d_lo, nullptr, n, 30, d_lo_s, d_pos1));
 		d_first = d_pos1;
 	}
-	if (morton_order)
+	if (morton_order || sc->hilbert) { // the keys are what this structure sorts by: only carried along
 		hipLaunchKernelGGL(k_gather_u32, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, d_pos1, (uint32_t)n, d_hi);
-	else
-		hipLaunchKernelGGL(k_hilbert_keys, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, d_first, (uint32_t)n, d_hi);
-	TREEE_LAUNCH_CHECK();
+		TREEE_LAUNCH_CHECK();
+	} else {
+		TREEE_TRY(hilbert_keys_dev(ctx, sc->d_keys, d_first, n, d_hi));
+	}
 	TREEE_TRY(sort_pairs_dev(ctx, d_hi, d_first, n, 30, fine->d_keys, d_pos2)); // stable: keeps the order inside a cell
 	hipLaunchKernelGGL(k_gather_rec, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_sorted, d_pos2, (uint32_t)n, fine->d_sorted, fine->d_perm);
 	TREEE_LAUNCH_CHECK();
@@ -1501,8 +1496,7 @@ int32_t build_segmented(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_se
 	TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
 	static const bool morton_order = getenv("TREEE_KNN_MORTON") != nullptr; // A/B hook
 	if (!morton_order && n) { // Hilbert order inside every segment (see refine_dense_cells)
-		hipLaunchKernelGGL(k_hilbert_keys, dim3(div_up(n, 256)), dim3(256), 0, st, d_keys_raw, nullptr, (uint32_t)n, d_keys_raw);
-		TREEE_LAUNCH_CHECK();
+		TREEE_TRY(hilbert_keys_dev(ctx, d_keys_raw, nullptr, n, d_keys_raw));
 		sc->hilbert = true;
 	}
 	TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, d_keys, d_perm));
@@ -1605,12 +1599,13 @@ int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, tree
 	treee_knn *t = new treee_knn; // (after reset(): nothing to leak if that fails)
 	t->device = ctx->device;
 	t->n_points = n;
-	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, nullptr, 0.0f, t->sc.get());
+	static const bool morton_order = getenv("TREEE_KNN_MORTON") != nullptr; // A/B hook (refine_dense_cells)
+	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, nullptr, 0.0f, t->sc.get(), false, /*hilbert_order=*/!morton_order); // one sort, in this structure's order
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);
 		return rc;
 	}
-	if (rc == TREEE_OK) rc = refine_dense_cells(ctx, t->sc, &t->sc);
+	if (rc == TREEE_OK) rc = refine_dense_cells(ctx, t->sc, &t->sc); // (crowded cells only)
 	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);

@@ -57,6 +57,19 @@ __global__ __launch_bounds__(256) void k_morton_keys_cube(const float *__restric
 	keys[i] = spread3(quant10(x, cx, size)) | (spread3(quant10(y, cy, size)) << 1) | (spread3(quant10(z, cz, size)) << 2);
 }
 
+// `out` may be `morton` itself when idx is null (one element per thread): neither is declared restrict
+__global__ __launch_bounds__(256) void k_hilbert_keys(const uint32_t *morton, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *out) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) out[i] = hilbert_of_morton(morton[idx ? idx[i] : i]);
+}
+
+int32_t hilbert_keys_dev(treee_ctx *ctx, const uint32_t *d_morton, const uint32_t *d_idx, uint64_t n, uint32_t *d_out) {
+	if (n == 0) return TREEE_OK;
+	hipLaunchKernelGGL(k_hilbert_keys, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_morton, d_idx, (uint32_t)n, d_out);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
 int32_t morton_keys_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3],
                         float size, uint32_t *d_keys) {
 	if (n == 0) return TREEE_OK;
@@ -487,7 +500,8 @@ int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, ui
 	return TREEE_OK;
 }
 
-int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc, bool fork_after_sort) {
+int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc, bool fork_after_sort,
+                           bool hilbert_order) {
 	sc->n = n;
 	sc->device = ctx->device;
 	sc->owner = ctx;
@@ -511,6 +525,10 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 		TREEE_LAUNCH_CHECK();
 	} else {
 		TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
+	}
+	if (hilbert_order) {
+		TREEE_TRY(hilbert_keys_dev(ctx, d_keys_raw, nullptr, n, d_keys_raw));
+		sc->hilbert = true;
 	}
 	TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, sc->d_keys, sc->d_perm));
 	// keys and permutation are final here: work that needs nothing else (the octree levels) may start on the context's
