@@ -1355,13 +1355,13 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_perm));
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_sorted));
 	uint32_t *d_lo = nullptr, *d_lo_s = nullptr, *d_pos1 = nullptr, *d_hi = nullptr, *d_pos2 = nullptr;
-	TREEE_TRY(ctx->alloc_t(n, &d_lo));
-	TREEE_TRY(ctx->alloc_t(n, &d_lo_s));
-	TREEE_TRY(ctx->alloc_t(n, &d_pos1));
 	TREEE_TRY(ctx->alloc_t(n, &d_hi));
 	TREEE_TRY(ctx->alloc_t(n, &d_pos2));
 	const uint32_t *d_first = nullptr; // order inside a cell: the low bits where cells are crowded, else the shared order
 	if (flag) {
+		TREEE_TRY(ctx->alloc_t(n, &d_lo));
+		TREEE_TRY(ctx->alloc_t(n, &d_lo_s));
+		TREEE_TRY(ctx->alloc_t(n, &d_pos1));
 		hipLaunchKernelGGL(k_fine_keys, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_sorted, (uint32_t)n, sc->corner[0], sc->corner[1], sc->corner[2],
 		                   sc->size, d_lo);
 		TREEE_LAUNCH_CHECK();
