@@ -116,3 +116,13 @@ def test_cpp_host_mirror_compiles_and_links():
     G.build()
     exe = G.build_host_mirror_test()
     assert os.path.exists(exe) and os.access(exe, os.X_OK)
+
+
+def test_integration_notes_show_a_binding_for_every_entry_point():
+    """INTEGRATION.md carries the reference-side (Rust extern "C") declaration of every symbol include/treee_hip.h exports"""
+    header = open(os.path.join(ROOT, "include", "treee_hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    symbols = sorted(set(re.findall(r"\b(treee_[a-z0-9_]+)\s*\(", header)))
+    assert len(symbols) >= 40
+    missing = [s for s in symbols if not re.search(r"\b" + s + r"\b", doc)]
+    assert not missing, missing
