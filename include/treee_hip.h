@@ -272,6 +272,23 @@ int32_t treee_decode_las_records_dev(treee_ctx *ctx, const uint8_t *d_rec, uint6
                                      uint32_t stride, const double scale[3],
                                      const double offset[3], const double center[3],
                                      float *d_xyz_out);
+/* LAZ sources (laz.rs:77-94,146-160).  The reference hands these to the crate `laz` 0.9.2 (not in the snapshot); this
+ * library restates the published LASzip format for LAS 1.0-1.3 files: pointwise chunked compressor, items POINT10 /
+ * GPSTIME11 / RGB12 / BYTE of version 2.  Host code on host threads, as in the reference.  PARITY UNPINNED: no LAZ file
+ * or tool exists where this was built (csrc/laz_codec.hip).
+ * treee_laz_chunk_table: `laz::laszip::ChunkTable::read_from` -- byte and point count of every chunk (the first chunk
+ * starts at offset_to_point_data + 8); chunk_size = the LAZ record's (0xFFFFFFFF: variable); point counts are clipped to
+ * total_points like laz.rs:88-89.  Call with byte_counts_out == NULL to learn *n_chunks_out. */
+int32_t treee_laz_chunk_table(const uint8_t *file, uint64_t file_len, uint64_t offset_to_point_data, uint32_t chunk_size,
+                              uint64_t total_points, uint64_t *byte_counts_out, uint64_t *point_counts_out, uint64_t cap,
+                              uint64_t *n_chunks_out);
+/* `decompress_many` of every chunk (laz.rs:146-160), one chunk per task on `threads` host threads (0 = all): chunk c
+ * (file[chunk_starts[c] ..+ chunk_bytes[c]), chunk_points[c] records) lands behind the chunks before it in dst; a record
+ * is the concatenation of the items (item_types / item_sizes / item_versions as in the LAZ record, n_items of them). */
+int32_t treee_laz_decompress_chunks(const uint8_t *file, uint64_t file_len, const uint16_t *item_types, const uint16_t *item_sizes,
+                                    const uint16_t *item_versions, uint32_t n_items, const uint64_t *chunk_starts,
+                                    const uint64_t *chunk_bytes, const uint64_t *chunk_points, uint64_t n_chunks, uint32_t threads,
+                                    uint8_t *dst, uint64_t dst_len);
 /* loading.rs:99: key = floor(p.y) as isize */
 int32_t treee_slice_keys(const float *xyz_aos, uint64_t n, int64_t *key_out);
 int32_t treee_slice_keys_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, int64_t *d_key_out);

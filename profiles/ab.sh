@@ -18,7 +18,7 @@ if [ "$mode" = build ]; then
     name=$1; flags=$2; shift 2
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $flags -c knn.hip -o /tmp/knn_$name.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $repo/abtmp/$name.so build/context.o build/radix_sort.o build/octree.o \
-      /tmp/knn_$name.o build/splat.o build/ingest.o build/shard.o build/calculations.o build/segmenting.o -Wl,-rpath,/opt/rocm/lib
+      /tmp/knn_$name.o build/splat.o build/ingest.o build/shard.o build/calculations.o build/segmenting.o build/laz_codec.o -Wl,-rpath,/opt/rocm/lib
     echo "built abtmp/$name.so ($flags)"
   done
 else

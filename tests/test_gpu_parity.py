@@ -467,6 +467,36 @@ def test_las_decode_bit_exact(T, oracle, stride, fmt):
         T.Laz(b"LASX" + img[4:])
 
 
+def test_laz_source_decodes_to_the_points_of_the_las_file(T, oracle):
+    """a LAZ image of a LAS file (made by the independent encoder of oracle/laz_encoder.py: parity with real LASzip files is
+    unpinned, tests/test_laz.py) goes through Laz::new / Laz::read / Chunk::read to the same f32 points, host and device"""
+    import struct
+
+    import torch
+
+    from oracle import laz_encoder as E
+    from treee_amd import synth
+
+    rng = np.random.default_rng(11)
+    ints = np.cumsum(rng.integers(-300, 320, (3_000, 3)), 0).astype(np.int32)
+    las = synth.las_bytes(ints, scale=(0.001, 0.002, 0.0005), offset=(500000.25, 4.5e6, 120.125), fmt=1, record_length=28)
+    laz = E.laz_bytes(las, chunk_size=1_000)
+    hdr = oracle.las_header_parse(las)
+    ref = oracle.decode_las_records(las[hdr.offset_to_point_data:], len(ints), 28, list(hdr.scale), list(hdr.offset), list(hdr.center))
+    src = T.Laz(laz)
+    assert src.total() == 3 and np.array_equal(src.center, np.array(list(hdr.center)))
+    host, dev = [], []
+    src.read(lambda c: host.append(c.read()))
+    assert np.array_equal(np.concatenate(host).view(np.uint32), ref.view(np.uint32))
+
+    def on_device(c):
+        c.slice = torch.from_numpy(np.ascontiguousarray(c.slice)).cuda()
+        dev.append(c.read().cpu().numpy())
+
+    src.read(on_device)
+    assert np.array_equal(np.concatenate(dev).view(np.uint32), ref.view(np.uint32))
+
+
 def test_slice_keys_and_binning(T, oracle):
     from treee_amd import synth
 

@@ -1,8 +1,10 @@
-"""Mirror of the ingest seam: treee/src/laz.rs (`Laz::new`, `Laz::read`, `Chunk::read`) for
-uncompressed LAS, and the y-slice binning of treee/src/loading.rs:91-115.
+"""Mirror of the ingest seam: treee/src/laz.rs (`Laz::new`, `Laz::read`, `Chunk::read`), and the y-slice binning of
+treee/src/loading.rs:91-115.
 
-LAZ arithmetic decompression is the third-party crate `laz` 0.9.2 and is not part of this
-path: a .laz source raises NotImplementedError."""
+LAZ sources: the reference hands decompression to the third-party crate `laz` 0.9.2 (not in the snapshot).  The library
+restates the published LASzip format for LAS 1.0-1.3 files (pointwise chunked, items POINT10 / GPSTIME11 / RGB12 / BYTE,
+version 2: treee_amd/csrc/laz_codec.hip, host threads like the reference's rayon tasks); layered LAS 1.4 items raise
+NotImplementedError.  Parity unpinned: no LAZ file or tool exists in the build container."""
 import struct
 
 import numpy as np
@@ -82,9 +84,15 @@ class Laz:
         self.point_length = h.point_data_record_length
         self.scale, self.offset = h.scale, h.offset
         self.center = (h.min + h.max) * 0.5 if center is None else np.asarray(center, dtype=np.float64)  # na::center
-        if self._has_laszip_vlr():
-            raise NotImplementedError("LAZ-compressed point data (crate `laz` 0.9.2) is outside this path")
         total = h.number_of_point_records
+        self.vlr = self._laszip_vlr()
+        self._records = None  # decompressed records of a LAZ source (filled by the first read)
+        if self.vlr is not None:  # laz.rs:80-94
+            self._laz_chunks(total)
+            self.min = (h.min - self.center).astype(np.float32)
+            self.max = (h.max - self.center).astype(np.float32)
+            self.world_offset = self.center
+            return
         need = h.offset_to_point_data + total * self.point_length
         if len(self.data) < need:  # the reference's read_exact fails on a short file (laz.rs:146-170)
             raise CorruptFile(f"file holds {len(self.data)} bytes, header promises {need}")
@@ -99,26 +107,80 @@ class Laz:
         self.max = (h.max - self.center).astype(np.float32)
         self.world_offset = self.center
 
-    def _has_laszip_vlr(self):
+    def _laszip_vlr(self):
         """laz.rs:77-79: the file is LAZ iff one of its variable length records is the laszip record
         (`laz` 0.9.2 `read_vlrs_and_get_laszip_vlr`: user id "laszip encoded", record id 22204); the scan starts
-        at header_size and walks number_of_variable_length_records 54-byte VLR headers."""
+        at header_size and walks number_of_variable_length_records 54-byte VLR headers.  Returns the record's fields
+        (compressor, coder, chunk_size, items [(type, size, version)]) or None."""
         h, pos = self.header, self.header.header_size
         for _ in range(h.number_of_variable_length_records):
             if pos + 54 > len(self.data):
-                return False
+                return None
             user_id = self.data[pos + 2 : pos + 18].split(b"\0", 1)[0]
             record_id, length = struct.unpack_from("<HH", self.data, pos + 18)
             if user_id == b"laszip encoded" and record_id == 22204:
-                return True
+                body = self.data[pos + 54 : pos + 54 + length]
+                if len(body) < 34:
+                    raise CorruptFile("laszip record shorter than its fixed part")
+                compressor, coder, _, _, _, _, chunk_size, _, _, n_items = struct.unpack_from("<HHBBHIIqqH", body, 0)
+                if len(body) < 34 + 6 * n_items:
+                    raise CorruptFile("laszip record shorter than its item list")
+                items = [struct.unpack_from("<HHH", body, 34 + 6 * i) for i in range(n_items)]
+                return {"compressor": compressor, "coder": coder, "chunk_size": chunk_size, "items": items}
             pos += 54 + length
-        return False
+        return None
+
+    def _laz_chunks(self, total):
+        """laz.rs:80-94: chunk table -> (start, point count) per chunk, the counts clipped to the header's total"""
+        import ctypes as C
+
+        v, h = self.vlr, self.header
+        if v["compressor"] != 2 or v["coder"] != 0:
+            raise NotImplementedError(f"LASzip compressor {v['compressor']} / coder {v['coder']}: only the pointwise chunked arithmetic form is built")
+        if any(ver != 2 for _, _, ver in v["items"]) or any(t not in (0, 6, 7, 8) for t, _, _ in v["items"]):
+            raise NotImplementedError(f"LASzip items {v['items']}: only POINT10, GPSTIME11, RGB12 and BYTE of version 2 are built")
+        if sum(s for _, s, _ in v["items"]) != self.point_length:
+            raise CorruptFile("the laszip items do not add up to the point record length")
+        buf = np.frombuffer(self.data, np.uint8)
+        nc = C.c_uint64(0)
+        _lib.check(_lib.lib().treee_laz_chunk_table(ptr(buf), len(buf), h.offset_to_point_data, v["chunk_size"], total, None, None, 0, C.byref(nc)))
+        nb, npnt = np.zeros(nc.value, np.uint64), np.zeros(nc.value, np.uint64)
+        if nc.value:
+            _lib.check(_lib.lib().treee_laz_chunk_table(ptr(buf), len(buf), h.offset_to_point_data, v["chunk_size"], total, ptr(nb), ptr(npnt), nc.value, C.byref(nc)))
+        self.chunks, self._chunk_bytes = [], []
+        start = h.offset_to_point_data + 8  # the reader's position after ChunkTable::read_from
+        for b, c in zip(nb.tolist(), npnt.tolist()):
+            self.chunks.append((start, c))
+            self._chunk_bytes.append(b)
+            start += b
+
+    def _decompress(self, threads=0):
+        v = self.vlr
+        items = np.asarray(v["items"], dtype=np.uint16).reshape(-1, 3)
+        types, sizes, versions = (np.ascontiguousarray(items[:, i]) for i in range(3))
+        starts = np.asarray([s for s, _ in self.chunks], dtype=np.uint64)
+        counts = np.asarray([c for _, c in self.chunks], dtype=np.uint64)
+        nbytes = np.asarray(self._chunk_bytes, dtype=np.uint64)
+        out = np.zeros(int(counts.sum()) * self.point_length, np.uint8)
+        buf = np.frombuffer(self.data, np.uint8)
+        _lib.check(_lib.lib().treee_laz_decompress_chunks(ptr(buf), len(buf), ptr(types), ptr(sizes), ptr(versions), len(items), ptr(starts), ptr(nbytes),
+                                                          ptr(counts), len(self.chunks), threads, ptr(out), len(out)))
+        self._records = out
 
     def total(self):
         return len(self.chunks)
 
-    def read(self, cb):
-        """Laz::read(cb): hands one Chunk per (start, length) to the callback."""
+    def read(self, cb, threads=0):
+        """Laz::read(cb): hands one Chunk per (start, length) to the callback.  A LAZ source is decompressed first, all
+        chunks at once on `threads` host threads (0 = all) -- the reference's rayon tasks (laz.rs:134-160)."""
+        if self.vlr is not None:
+            if self._records is None:
+                self._decompress(threads)
+            o = 0
+            for _, l in self.chunks:
+                cb(Chunk(self._records[o : o + l * self.point_length], self.point_length, self.offset, self.scale, self.center))
+                o += l * self.point_length
+            return
         for s, l in self.chunks:
             cb(Chunk(self.data[s : s + l * self.point_length], self.point_length, self.offset, self.scale, self.center))
 
