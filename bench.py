@@ -486,6 +486,36 @@ def out_of_core_stage(dev, n, proj, tiles=67):
         ts.close()
         res[name] = {"points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1),
                      "pcie_GBps": round(r["points"] * 20 / dt / 1e9, 1)}
+    # the same stream from LAZ tiles (configs[4] as BASELINE.json words it): decompressed on the host's threads, one tile
+    # ahead of the GPU -- what bounds it is the host, as in the reference (laz.rs:134-160)
+    import copy
+
+    t0 = time.perf_counter()
+    p, _ = synth.forest_cloud_torch(n, dev, plot=PLOT, seed=synth.SEED_FOREST + 100)
+    ztile = stream.laz_tile_from_cloud(p)
+    del p
+    enc_s = time.perf_counter() - t0
+
+    def zgen(count):
+        for i in range(count):
+            z = copy.copy(ztile)  # (placed through the LAS header offset like the tiles above; the image is shared)
+            z.offset, z.center = np.asarray(((i % 9) * PLOT, (i // 9) * PLOT, 0.0)), np.asarray((4 * PLOT, 3.5 * PLOT, 0.0))
+            yield z
+
+    ztiles = min(tiles, 24)
+    laz_threads = min(os.cpu_count() or 1, 32)  # (a one-GPU box grants ~16 cores whatever nproc says: more threads only add jitter)
+    res["laz"] = {"workload": f"{ztiles} LAZ tiles x {n} points (format 0, 50 000-point chunks), {len(ztile.src.data) / n:.2f} B/point compressed",
+                  "host_threads": laz_threads, "encode_seconds_per_tile": round(enc_s, 2)}
+    for name, k in (("octree_splat", 0), ("octree_knn_splat", K)):
+        ts = stream.TileStream(dev, n, width=W, height=H, knn_k=k)
+        ts.laz_threads = laz_threads
+        ts.run(zgen(2), view, proj, env)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = ts.run(zgen(ztiles), view, proj, env)
+        dt = time.perf_counter() - t0
+        ts.close()
+        res["laz"][name] = {"points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1)}
     return res
 
 

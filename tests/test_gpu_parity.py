@@ -637,6 +637,38 @@ def test_tile_stream_equals_tile_by_tile(T, oracle, knn_k):
     assert np.array_equal(ref_xyz.view(np.uint32), seen[0][1].cpu().numpy().view(np.uint32))
 
 
+def test_tile_stream_of_laz_tiles_equals_the_las_stream(T):
+    """the same tiles as LAZ images (decompressed on host threads one tile ahead, pinned staging) and mixed with LAS tiles:
+    same octrees, same frame, bit for bit"""
+    import torch
+
+    from treee_amd import stream, synth
+
+    w, h = 320, 200
+    las, lazt = [], []
+    for i, n in enumerate((70_001, 50_000, 64, 30_000)):
+        pts, _ = synth.forest_cloud_torch(n, "cuda", plot=15.0, seed=synth.SEED_FOREST + i)
+        t = stream.las_tile_from_cloud(pts)
+        las.append(stream.Tile(t.records, t.n, t.stride, t.scale, (i * 15.0, 0.0, 0.0), (15.0, 0.0, 5.0)))
+        z = stream.laz_tile_from_cloud(pts, chunk_size=20_000)
+        z.offset, z.center = las[-1].offset, las[-1].center
+        assert z.n == n and len(z.src.data) < 0.8 * n * 20
+        lazt.append(z)
+    cam = T.Camera3D(w / h)
+    proj, view, env = cam.projection(), T.view_from_transform(T.rotation_x(-0.5) @ T.translation(0.0, 0.0, 60.0)), T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+    frames, nodes = [], []
+    for tiles in (las, lazt, [lazt[0], las[1], lazt[2], lazt[3]]):
+        ts = stream.TileStream("cuda:0", 80_000, width=w, height=h, knn_k=0)
+        seen = []
+        res = ts.run(tiles, view, proj, env, on_tile=lambda i, tile, oc, xyz: seen.append(oc.array("nodes")))
+        frames.append(ts.packed.clone())
+        nodes.append(seen)
+        ts.close()
+        assert res["points"] == sum(t.n for t in las)
+    for f, nd in zip(frames[1:], nodes[1:]):
+        assert torch.equal(f, frames[0]) and all(np.array_equal(a, b) for a, b in zip(nd, nodes[0]))
+
+
 # ---------------------------------------------------------------- kNN edge cases (sorted-32 kernel paths)
 @pytest.mark.parametrize("k", [1, 2, 7, 15, 16, 17, 31, 32, 33, 48, 64, 65])
 def test_knn_every_small_k(T, oracle, k):

@@ -178,3 +178,23 @@ def test_laz_round_trip_of_noise_and_extremes(T, fmt, rl):
     got = []
     T.Laz(E.laz_bytes(las, chunk_size=600)).read(lambda ch: got.append(np.asarray(ch.slice).reshape(-1, rl)), threads=4)
     assert np.array_equal(np.concatenate(got), rec)
+
+
+@pytest.mark.parametrize("fmt,rl", [(0, 20), (1, 28), (2, 26), (3, 34), (3, 41)])
+def test_library_encoder_writes_the_bytes_of_the_independent_one(T, fmt, rl):
+    """treee_laz_encode (C++, fixtures / benchmark input) against oracle/laz_encoder.py (Python): the same file, byte for
+    byte -- three statements of the format (two encoders, one decoder) agree.  Then noise, which needs the retry path."""
+    from oracle import laz_encoder as E
+    from treee_amd.laz import laz_encode
+
+    rec = np.concatenate([flight_lines(1_700, 40 + fmt, fmt, rl), np.random.default_rng(fmt).integers(0, 256, (300, rl), dtype=np.uint8)])
+    las = las_image(T, rec, fmt)
+    assert laz_encode(las, chunk_size=450, threads=3) == E.laz_bytes(las, chunk_size=450)
+    noise = las_image(T, np.random.default_rng(9).integers(0, 256, (4_000, rl), dtype=np.uint8), fmt)
+    laz = laz_encode(noise, chunk_size=1_000)
+    got = []
+    T.Laz(laz).read(lambda ch: got.append(np.asarray(ch.slice).reshape(-1, rl)))
+    (off,) = struct.unpack_from("<I", noise, 96)
+    assert np.concatenate(got).tobytes() == noise[off:]
+    with pytest.raises(RuntimeError):
+        laz_encode(b"LASX" + las[4:])

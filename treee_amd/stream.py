@@ -1,5 +1,5 @@
 """Out-of-core tile stream (BASELINE.json configs[4]: a cloud far larger than one wants resident, streamed as
-uncompressed LAS tiles): host LAS records -> HBM over PCIe on a copy stream, overlapped with the previous
+uncompressed LAS tiles, or as LAZ tiles decompressed on host threads one tile ahead): host LAS records -> HBM over PCIe on a copy stream, overlapped with the previous
 tile's decode -> Morton sort -> octree/LOD [-> kNN + curvature] -> splat on the compute stream.
 
 What the reference does with such a file: `Laz::read` hands 50 000-point chunks to worker threads
@@ -30,6 +30,34 @@ class Tile:
         self.scale, self.offset, self.center = (np.ascontiguousarray(a, dtype=np.float64) for a in (scale, offset, center))
 
 
+class LazTile:
+    """One LAZ-compressed tile: `image` is the file (bytes).  The stream decompresses it on host threads into a pinned
+    staging buffer (treee_laz_decompress_chunks: what the reference's rayon tasks do, laz.rs:134-160) while the GPU works on
+    the tile before it."""
+
+    def __init__(self, image, center=None):
+        from .laz import Laz
+
+        self.src = Laz(image, center)
+        self.n = int(sum(c for _, c in self.src.chunks))
+        self.stride = int(self.src.point_length)
+        self.scale, self.offset, self.center = (np.ascontiguousarray(a, dtype=np.float64) for a in (self.src.scale, self.src.offset, self.src.center))
+        self.records = None  # set by the stream: the pinned buffer the records were decompressed into
+
+    def decompress_into(self, out, threads=0):
+        """out: uint8 tensor (pinned host memory) of at least n * stride bytes"""
+        src, v = self.src, self.src.vlr
+        items = np.asarray(v["items"], dtype=np.uint16).reshape(-1, 3)
+        types, sizes, versions = (np.ascontiguousarray(items[:, i]) for i in range(3))
+        starts = np.asarray([s for s, _ in src.chunks], dtype=np.uint64)
+        counts = np.asarray([c for _, c in src.chunks], dtype=np.uint64)
+        nbytes = np.asarray(src._chunk_bytes, dtype=np.uint64)
+        buf = np.frombuffer(src.data, np.uint8)
+        _lib.check(_lib.lib().treee_laz_decompress_chunks(ptr(buf), len(buf), ptr(types), ptr(sizes), ptr(versions), len(items), ptr(starts), ptr(nbytes),
+                                                          ptr(counts), len(src.chunks), threads, ptr(out), self.n * self.stride))
+        self.records = out
+
+
 class TileStream:
     def __init__(self, device, max_points, max_stride=20, width=1920, height=1080, knn_k=0, leaf_cap=256, lod_cap=256):
         import torch
@@ -50,13 +78,16 @@ class TileStream:
         self.leaf_cap, self.lod_cap = leaf_cap, lod_cap
         self.copied = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
+        self.pinned = None  # two pinned staging buffers for LAZ tiles, allocated when the first one arrives
+        self.pool = None  # one worker: the next LAZ tile is decompressed (on the library's host threads) while this one runs
+        self.laz_threads = 0
 
     def run(self, tiles, view, proj, env, on_tile=None):
         """Streams `tiles` (an iterable of Tile).  Returns a dict with the tile roots (corner, size, node / lod
         counts per tile) and the totals; the frame is left in self.packed (depth_bits << 32 | global index)."""
         torch, lib = self.torch, _lib.lib()
         roots, total, index_base = [], 0, 0
-        it = iter(tiles)
+        it = self._decoded(iter(tiles))
         pending = next(it, None)
         if pending is not None:
             self._upload(pending, 0, first=True)
@@ -101,6 +132,43 @@ class TileStream:
         self.compute.synchronize()
         return {"tiles": roots, "points": total}
 
+    def _decoded(self, tiles):
+        """passes LAS tiles through; a LAZ tile is handed on once its records are in pinned memory, and the decompression
+        of the LAZ tile after it has been started by then (one tile ahead, alternating staging buffers)"""
+        torch = self.torch
+        ahead, k = None, 0  # (tile, future) being decompressed
+
+        def start(tile):
+            nonlocal k
+            from concurrent.futures import ThreadPoolExecutor
+
+            if self.pinned is None:
+                self.pinned = [torch.empty((self.max_points * self.max_stride,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+                self.pinned_read = [torch.cuda.Event() for _ in range(2)]  # the H2D copy that last read each staging buffer
+                self.pool = ThreadPoolExecutor(max_workers=1)
+            assert tile.n <= self.max_points and tile.stride <= self.max_stride
+            slot = k & 1
+            k += 1
+            self.pinned_read[slot].synchronize()  # (two LAZ tiles ago)
+            return tile, self.pool.submit(tile.decompress_into, self.pinned[slot], self.laz_threads)
+
+        for tile in tiles:
+            if isinstance(tile, LazTile):
+                nxt = start(tile)
+                if ahead is not None:
+                    ahead[1].result()
+                    yield ahead[0]
+                ahead = nxt
+            else:
+                if ahead is not None:
+                    ahead[1].result()
+                    yield ahead[0]
+                    ahead = None
+                yield tile
+        if ahead is not None:
+            ahead[1].result()
+            yield ahead[0]
+
     def _upload(self, tile, slot, first):
         torch = self.torch
         nbytes = tile.n * tile.stride
@@ -110,8 +178,14 @@ class TileStream:
                 self.copy.wait_event(self.consumed[slot])
             self.raw[slot][:nbytes].copy_(tile.records[:nbytes], non_blocking=True)
             self.copied[slot].record(self.copy)
+            if self.pinned is not None:
+                for k in range(2):
+                    if tile.records is self.pinned[k]:
+                        self.pinned_read[k].record(self.copy)
 
     def close(self):
+        if self.pool is not None:
+            self.pool.shutdown()
         self.ctx.close()
 
 
@@ -129,3 +203,18 @@ def las_tile_from_cloud(xyz, scale=0.001, stride=20, pin=True):
     host = torch.empty((n * stride,), dtype=torch.uint8, pin_memory=pin)
     host.copy_(rec.view(torch.uint8).reshape(-1))
     return Tile(host, n, stride, (scale,) * 3, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+
+
+def laz_tile_from_cloud(xyz, scale=0.001, stride=20, chunk_size=50_000, threads=0):
+    """the same records as las_tile_from_cloud, LAZ-compressed (treee_laz_encode) -- a LazTile"""
+    import struct
+
+    from .laz import laz_encode
+    from .synth import las_bytes
+
+    t = las_tile_from_cloud(xyz, scale, stride, pin=False)
+    img = bytearray(las_bytes(np.zeros((t.n, 3), np.int32), scale=(scale,) * 3, fmt=0, record_length=stride))
+    (off,) = struct.unpack_from("<I", img, 96)
+    img[off:] = t.records.numpy().tobytes()
+    struct.pack_into("<6d", img, 179, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)  # (bbox unused here: the tile's centre is passed explicitly)
+    return LazTile(laz_encode(bytes(img), chunk_size=chunk_size, threads=threads), center=(0.0, 0.0, 0.0))
