@@ -37,6 +37,9 @@ int32_t set_err(int32_t code, const char *fmt, ...);
 #define TREEE_LAUNCH_CHECK() TREEE_HIP(hipGetLastError())
 
 inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+// host threads worth starting for the library's host-side phases (segmenting, LAZ): the hardware's count, or the CPU quota
+// of the cgroup when that is smaller (a container that shows 256 CPUs and grants 16 only gains jitter from 256 threads)
+unsigned host_threads();
 
 // ---- device helpers --------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -4,7 +4,25 @@
 #include <mutex>
 #include <set>
 
+#include <cstdio>
+#include <thread>
+
 namespace treee {
+
+unsigned host_threads() {
+	unsigned n = std::thread::hardware_concurrency();
+	if (n == 0) n = 1;
+	if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota> <period>" or "max <period>"
+		long long quota = 0, period = 0;
+		if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+			const unsigned q = (unsigned)((quota + period - 1) / period);
+			if (q >= 1 && q < n) n = q;
+		}
+		std::fclose(f);
+	}
+	return n;
+}
+
 
 static thread_local char g_err[512] = "";
 

@@ -1038,7 +1038,7 @@ int32_t treee_laz_decompress_chunks(const uint8_t *file, uint64_t file_len, cons
 		std::vector<std::unique_ptr<Item>> probe;
 		TREEE_TRY(make_items(item_types, item_sizes, item_versions, n_items, probe));
 	}
-	uint32_t nt = threads ? threads : std::thread::hardware_concurrency();
+	uint32_t nt = threads ? threads : treee::host_threads();
 	if (nt == 0) nt = 1;
 	if ((uint64_t)nt > n_chunks) nt = (uint32_t)n_chunks;
 	std::atomic<uint64_t> next{0};
@@ -1099,7 +1099,7 @@ int32_t treee_laz_encode(const uint8_t *las, uint64_t las_len, uint32_t chunk_si
 	const uint64_t n_chunks = (n + chunk_size - 1) / chunk_size;
 	std::vector<std::vector<uint8_t>> chunks(n_chunks);
 	{
-		uint32_t nt = threads ? threads : std::thread::hardware_concurrency();
+		uint32_t nt = threads ? threads : treee::host_threads();
 		if (nt == 0) nt = 1;
 		if ((uint64_t)nt > n_chunks) nt = (uint32_t)(n_chunks ? n_chunks : 1);
 		std::atomic<uint64_t> next{0};

@@ -322,7 +322,7 @@ int32_t treee_segment_slices(const float *xyz, uint64_t n, const float bbox_min_
 		};
 		std::vector<Layer> layer(layers); // layer[0] = top slice
 		auto parallel_for = [&](const std::function<void(size_t)> &fn) {
-			unsigned workers = std::thread::hardware_concurrency();
+			unsigned workers = treee::host_threads();
 			if (workers == 0) workers = 1;
 			if (workers > layers) workers = (unsigned)layers;
 			std::atomic<size_t> next{0};
