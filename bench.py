@@ -400,7 +400,7 @@ def segmentation_stage(sample=1_500_000):
     sg, nseg = T.segment_slices(host, seed=1)
     dt = time.perf_counter() - t0
     return {"workload": f"{sample}-point forest patch ({plot:.0f} m), max_distance 0.75: slices -> hulls -> centroid hand-off -> Voronoi cells -> ids",
-            "seconds": round(dt, 3), "Mpoints_per_s": round(sample / dt / 1e6, 3), "segments": int(nseg) - 1, "host_threads": os.cpu_count(),
+            "seconds": round(dt, 3), "Mpoints_per_s": round(sample / dt / 1e6, 3), "segments": int(nseg) - 1, "host_threads": _host_threads(),
             "assigned_fraction": round(float((sg > 0).mean()), 4)}
 
 
@@ -503,13 +503,7 @@ def out_of_core_stage(dev, n, proj, tiles=67):
             yield z
 
     ztiles = min(tiles, 24)
-    laz_threads = os.cpu_count() or 1  # what the library starts by itself: the hardware's threads or the cgroup's CPU quota
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            laz_threads = max(1, min(laz_threads, -(-int(quota) // int(period))))
-    except (OSError, ValueError):
-        pass
+    laz_threads = _host_threads()
     res["laz"] = {"workload": f"{ztiles} LAZ tiles x {n} points (format 0, 50 000-point chunks), {len(ztile.src.data) / n:.2f} B/point compressed",
                   "host_threads": laz_threads, "encode_seconds_per_tile": round(enc_s, 2)}
     for name, k in (("octree_splat", 0), ("octree_knn_splat", K)):
@@ -523,6 +517,19 @@ def out_of_core_stage(dev, n, proj, tiles=67):
         ts.close()
         res["laz"][name] = {"points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1)}
     return res
+
+
+def _host_threads():
+    """what the library's host-side phases start by themselves (treee::host_threads): the hardware's threads, or the cgroup's
+    CPU quota when that is smaller"""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _latest_profile(pattern):
