@@ -584,7 +584,7 @@ def cpu_baseline(sample):
     plot = PLOT * (sample / 15_000_000) ** 0.5
     d_pts, d_seg = synth.forest_cloud_torch(sample, "cuda" if torch.cuda.is_available() else "cpu", plot=plot)
     pts, seg = d_pts.cpu().numpy(), d_seg.cpu().numpy().astype(np.uint32)
-    cores = os.cpu_count() or 1
+    cores = _host_threads()  # (the CPUs this process may really use: a one-GPU box shows 256 and grants 16)
     t0 = time.perf_counter()
     mn = pts.min(0)
     keys = O.morton_keys(pts, mn, float((pts.max(0) - mn).max()))
