@@ -992,6 +992,7 @@ int32_t treee_laz_chunk_table(const uint8_t *file, uint64_t file_len, uint64_t o
 	std::memcpy(&version, file + pos, 4);
 	std::memcpy(&number, file + pos + 4, 4);
 	if (version != 0) return treee::set_err(TREEE_ERR_UNSUPPORTED, "LAZ: chunk table version %u", version);
+	if ((uint64_t)number > file_len) return treee::set_err(TREEE_ERR_INVALID, "LAZ: the chunk table claims %u chunks in a file of %llu bytes", number, (unsigned long long)file_len);
 	*n_chunks_out = number;
 	if (number == 0 || (!byte_counts_out && !point_counts_out)) return TREEE_OK; // (a call that only asks for the count)
 	if (!byte_counts_out || !point_counts_out || cap < number) return treee::set_err(TREEE_ERR_INVALID, "LAZ: %u chunks, room for %llu", number, (unsigned long long)cap);
