@@ -58,9 +58,13 @@ __global__ __launch_bounds__(256) void k_morton_keys_cube(const float *__restric
 }
 
 // `out` may be `morton` itself when idx is null (one element per thread): neither is declared restrict
+__constant__ uint16_t c_hilbert_lut[24 * 8] = {TREEE_HILBERT_LUT_INIT};
 __global__ __launch_bounds__(256) void k_hilbert_keys(const uint32_t *morton, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *out) {
+	__shared__ uint16_t s_lut[24 * 8];
+	if (threadIdx.x < 24 * 8) s_lut[threadIdx.x] = c_hilbert_lut[threadIdx.x];
+	__syncthreads();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i < n) out[i] = hilbert_of_morton(morton[idx ? idx[i] : i]);
+	if (i < n) out[i] = hilbert_of_morton_lut(morton[idx ? idx[i] : i], s_lut);
 }
 
 int32_t hilbert_keys_dev(treee_ctx *ctx, const uint32_t *d_morton, const uint32_t *d_idx, uint64_t n, uint32_t *d_out) {
