@@ -32,7 +32,9 @@ W, H = 1920, 1080
 PLOT = 200.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # algorithmic bytes per point (SURVEY.md section 8 D / BASELINE.md section 3)
-BYTES = {"keys_sort_octree": 20 + 68 + 40, "knn_curve": 340, "splat": 16}
+# algorithmic bytes per point; the kNN structure's own order adds a key conversion (8), a second sort (68), the
+# gather of the 16-byte records (4 + 16 + 16 + 4) and the bucket boxes (16)
+BYTES = {"keys_sort_octree": 20 + 68 + 40, "keys_sort_octree_knn_structure": 20 + 68 + 40 + 8 + 68 + 40 + 16, "knn_curve": 340, "splat": 16}
 
 
 def parse():
@@ -43,6 +45,7 @@ def parse():
     ap.add_argument("--points", type=int, default=15_000_000, help="points per GPU")
     ap.add_argument("--plot", type=float, default=PLOT, help="edge of the square tile in metres (632 with --points 150000000 keeps the density)")
     ap.add_argument("--halo", type=float, default=2.0)
+    ap.add_argument("--no-overlap", action="store_true", help="build the octree's node table and the kNN structure one after the other on one stream")
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="points of the CPU-baseline sample (about 10-30 s of oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (ingest, per-segment kNN, eye-dome, out-of-core stream): profiling runs")
@@ -109,6 +112,9 @@ def main():
     ids = torch.empty((H, W), dtype=torch.int32, device=dev)
     curve = torch.empty((n + n // 8,), dtype=torch.float32, device=dev)
     ctx.reserve(int(n * 1.15) * 48 + (64 << 20))
+    overlap = not args.no_overlap
+    side = torch.cuda.Stream(dev) if overlap else None
+    ctx2 = T.Context(dev, side) if overlap else None
     stages = Stage()
     halo = args.halo
     state = {}
@@ -123,9 +129,20 @@ def main():
             cloud = pts
         m = cloud.shape[0]
         free_state()  # previous step's handles: blocks return to the context pool, stream-ordered, no sync
-        # ONE Morton sort per step: the octree is built over the shard plus its boundary ghosts and the
-        # kNN structure shares that sorted cloud by reference
-        oc = stages.run("keys_sort_octree", lambda: T.Octree(cloud, ctx=ctx), record)
+        # ONE Morton sort per step, two consumers: the kNN structure (its own Hilbert re-sort + box tree) is built on this
+        # stream while the octree's node table -- ~50 small dependent launches -- is completed on a second one
+        # (treee_sort_dev / treee_knn_from_octree_dev / treee_octree_complete_dev); --no-overlap builds them one after the other
+        if overlap:
+            def both():
+                o = T.Octree(cloud, ctx=ctx, defer=True)
+                t = T.KDTree.from_octree(o, ctx)
+                o.complete(ctx2)
+                torch.cuda.current_stream().wait_stream(side)
+                return o, t
+
+            oc, tree_early = stages.run("keys_sort_octree_knn_structure", both, record)
+        else:
+            oc = stages.run("keys_sort_octree", lambda: T.Octree(cloud, ctx=ctx), record)
         pending = None
         if world > 1:
             # The environment culls nothing (min 0, max u32::MAX), so the packed (depth, index) frame depends on
@@ -137,7 +154,7 @@ def main():
                 return D.reduce_packed_min_async(packed)
 
             pending = stages.run("splat", draw, record)
-        tree = stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
+        tree = tree_early if overlap else stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
         cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
         # at N > 1 only the shard's own points are queried: the ghosts behind them are neighbours, not queries
         stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv, n_own=n if world > 1 else None), record)
@@ -213,6 +230,8 @@ def main():
         achieved = BYTES["knn_curve"] * m_knn / (knn_ms * 1e-3) / 1e9
         stage_roof = {}
         for name, b in BYTES.items():
+            if name not in ms:
+                continue
             pts_in = m_knn if name == "knn_curve" else n
             extra = 24 * W * H if name == "splat" else 0
             gbs = (b * pts_in + extra) / (ms[name] * 1e-3) / 1e9
@@ -255,7 +274,7 @@ def main():
                 "kernel_ms": round(knn_ms, 3),
             },
             "stages": stage_roof,
-            "end_to_end_GBps": round((sum(BYTES.values()) * n + 24 * W * H) / (elapsed / args.steps) / 1e9 * world, 1),
+            "end_to_end_GBps": round(((BYTES["keys_sort_octree"] + BYTES["knn_curve"] + BYTES["splat"]) * n + 24 * W * H) / (elapsed / args.steps) / 1e9 * world, 1),
         }
         if world == 1 and n == 15_000_000 and not args.no_extras:
             out["hbm_copy_GBps"] = measured_copy_gbps(dev)
