@@ -68,6 +68,9 @@ class TileStream:
         self.copy = torch.cuda.Stream(self.device)
         self.ctx = Context(self.device.index, self.compute)
         self.ctx.reserve(int(max_points * 1.1) * 64 + (64 << 20))
+        # with kNN on, a tile's octree node table is completed on a side stream under the kNN structure's own build
+        self.side = torch.cuda.Stream(self.device) if knn_k else None
+        self.ctx2 = Context(self.device.index, self.side) if knn_k else None
         self.max_points, self.max_stride = int(max_points), int(max_stride)
         self.raw = [torch.empty((self.max_points * self.max_stride,), dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.xyz = torch.empty((self.max_points, 3), dtype=torch.float32, device=self.device)
@@ -108,13 +111,16 @@ class TileStream:
                 _lib.check(lib.treee_decode_las_records_dev(self.ctx.handle, ptr(self.raw[slot]), n, tile.stride, ptr(tile.scale),
                                                             ptr(tile.offset), ptr(tile.center), ptr(xyz)))
                 self.consumed[slot].record(self.compute)  # the staging buffer may be overwritten from here on
-                oc = Octree(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx)
                 if self.knn_k:
+                    oc = Octree(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx, defer=True)
                     tree = KDTree.from_octree(oc, self.ctx)
+                    oc.complete(self.ctx2)
+                    self.compute.wait_stream(self.side)
                     tree.curvature_dev(self.knn_k, F32_MAX, self.ctx, out=self.curve[:n])
                     _lib.check(lib.treee_map_to_u32_dev(self.ctx.handle, ptr(self.curve), n, ptr(self.value)))
                     tree.close()
                 else:
+                    oc = Octree(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx)
                     self.value[:n].fill_(0)
                 if index_base + n >= 0xFFFFFFFF:
                     # the packed frame carries 32-bit global point ids and 0xFFFFFFFF is its "no point" sentinel
@@ -186,6 +192,8 @@ class TileStream:
     def close(self):
         if self.pool is not None:
             self.pool.shutdown()
+        if self.ctx2 is not None:
+            self.ctx2.close()
         self.ctx.close()
 
 
