@@ -417,7 +417,7 @@ struct GpsTime11 : Item {
 		std::memset(multi_extreme_counter, 0, sizeof(multi_extreme_counter));
 		std::memcpy(&last_gpstime[0], first, 8);
 	}
-	void add(int32_t diff) { last_gpstime[last] = (uint64_t)((int64_t)last_gpstime[last] + (int64_t)diff); }
+	void add(int32_t diff) { last_gpstime[last] += (uint64_t)(int64_t)diff; } // (wraps like the i64 sum it restates; damaged streams get here with anything)
 	void full(Decoder &d) { // a time that fits no sequence: upper half predicted from the current sequence, lower half raw
 		next = (next + 1) & 3;
 		last_gpstime[next] = (uint64_t)(uint32_t)ic.decompress(d, (int32_t)(last_gpstime[last] >> 32), 8);
