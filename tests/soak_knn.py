@@ -1,0 +1,43 @@
+"""Randomised soak of the kNN paths against the oracle (not collected by pytest: run by hand on the GPU box).
+
+    python tests/soak_knn.py <seed> <seconds>
+
+Clouds of 1 .. 70 000 points (cubes, planes, lines, clusters, lattices, duplicates; offsets up to 3e5), k from 1 to 100, four
+radii, queries on and off the points; every case through the SURVEY H2 contract (counts and distance bits identical, indices
+inside their tie groups).  Round 2: 31 000 cases, clean."""
+import sys, time
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import treee_amd as T
+from oracle import oracle as O
+from conftest import check_knn_contract
+O.build()
+F32_MAX = float(np.finfo(np.float32).max)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+t0 = time.time(); cases = 0; ties = 0
+while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 90:
+    n = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 200, 257, 1000, 4097, 20000, 70000]))
+    shape = rng.choice(['cube', 'plane', 'line', 'clusters', 'lattice', 'dups'])
+    if shape == 'cube': p = rng.random((n, 3)) * rng.choice([1e-3, 1.0, 1e4])
+    elif shape == 'plane': p = rng.random((n, 3)) * [100, 1e-4, 100]
+    elif shape == 'line': p = np.outer(rng.random(n), [3.0, 1.0, -2.0]) + rng.normal(0, 1e-5, (n, 3))
+    elif shape == 'clusters': p = rng.normal(0, 0.01, (n, 3)) + rng.integers(0, 5, (n, 1)) * [10.0, 0, 3.0]
+    elif shape == 'lattice': p = rng.integers(0, 12, (n, 3)) * 0.25
+    else: p = np.repeat(rng.random((max(1, n // 40), 3)), 40, 0)[:n]; p = np.concatenate([p, rng.random((n - len(p), 3))]) if len(p) < n else p
+    p = (p + rng.choice([0.0, 1000.0, -3e5])).astype(np.float32)
+    k = int(rng.choice([1, 2, 5, 16, 17, 31, 32, 33, 64, 65, 100]))
+    maxd = float(rng.choice([F32_MAX, 1.0, 1e-6, 0.07]))
+    nq = min(n, 400)
+    qsel = rng.choice(n, nq, replace=False)
+    q = p[qsel] if rng.random() < 0.7 else (p[qsel] + rng.normal(0, 0.05, (nq, 3))).astype(np.float32)
+    r_ent, r_cnt = O.KDTree(p).k_nearest_batch(q, k, maxd)
+    tree = T.KDTree.new(p)
+    g_ent, g_cnt = tree.k_nearest_batch(q, k, maxd)
+    try:
+        ties += check_knn_contract(p, q, g_ent, g_cnt, r_ent, r_cnt)
+    except AssertionError as e:
+        print('FAIL', n, shape, k, maxd, e); np.save(os.path.join(ROOT, 'gpurun_out', 'soak_fail.npy'), p); raise
+    tree.close(); cases += 1
+print('cases', cases, 'tie-resolved indices', ties)
