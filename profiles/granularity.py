@@ -1,6 +1,6 @@
 """How many candidate points does a query NEED at bucket sizes 64 / 32 / 16 (final radii, exact box tests), what does the
 neediest lane of a wave need, and what is the wave's union?  CPU analysis (scipy) on a 0.94 M-point patch at the 15 M
-configuration's density; uses the oracle for the Hilbert keys.  Results: profiles/README.md, "Would finer candidate
+configuration's density; Results: profiles/README.md, "Would finer candidate
 granularity pay?"."""
 import sys, time
 import os
@@ -8,12 +8,38 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from scipy.spatial import cKDTree
 from treee_amd import synth
-from oracle import oracle as O
-O.build()
+def hilbert_keys(points, corner, size):
+    """30-bit Hilbert index of the 2^-10 cells (Skilling 2004), vectorised -- the order the kNN structure cuts its buckets in"""
+    q = np.clip(np.floor((points - corner) / size * 1024.0), 0, 1023).astype(np.int64)
+    X = [q[:, 0].copy(), q[:, 1].copy(), q[:, 2].copy()]
+    Q = 512
+    while Q > 1:
+        P = Q - 1
+        for i in range(3):
+            hit = (X[i] & Q) != 0
+            X[0] = np.where(hit, X[0] ^ P, X[0])
+            t = np.where(hit, 0, (X[0] ^ X[i]) & P)
+            X[0] ^= t
+            X[i] ^= t
+        Q >>= 1
+    X[1] ^= X[0]
+    X[2] ^= X[1]
+    t = np.zeros_like(X[0])
+    Q = 512
+    while Q > 1:
+        t = np.where((X[2] & Q) != 0, t ^ (Q - 1), t)
+        Q >>= 1
+    X = [x ^ t for x in X]
+    h = np.zeros_like(X[0])
+    for b in range(9, -1, -1):
+        h = (h << 3) | (((X[0] >> b) & 1) << 2) | (((X[1] >> b) & 1) << 1) | ((X[2] >> b) & 1)
+    return h
+
+
 n = 940_000
 pts, _ = synth.forest_cloud(n, plot=50.0)
 mn = pts.min(0); size = float((pts.max(0) - mn).max())
-h = O.hilbert_keys(pts, mn, size)
+h = hilbert_keys(pts.astype(np.float64), mn.astype(np.float64), size)
 order = np.argsort(h, kind='stable')
 P = pts[order].astype(np.float64)
 tree = cKDTree(P)
