@@ -495,6 +495,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef TREEE_NG
 #define TREEE_NG 4
 #endif
+#ifndef TREEE_GROUP
+#define TREEE_GROUP 56 // listed buckets whose boxes are in LDS at a time: 56 and not 64 keeps the workgroup's LDS at 12 800 bytes (below)
+#endif
 #ifndef TREEE_ORDER_RANGE
 #define TREEE_ORDER_RANGE 128
 #endif
@@ -522,7 +525,13 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 	__shared__ __attribute__((aligned(16))) float tile[3][BUCKET]; // SoA candidate tile (x[], y[], z[])
 	__shared__ uint32_t buf[2 * SBUF * 64]; // [pos | distance bits][slot][lane]: conflict-free per slot
 	__shared__ uint32_t s_list[LIST_CAP];
-	__shared__ __attribute__((aligned(16))) float4 s_gbox[64][2]; // boxes of the current group of listed buckets
+	constexpr uint32_t GROUP = TREEE_GROUP; // listed buckets whose boxes are in LDS at a time
+	__shared__ __attribute__((aligned(16))) float4 s_gbox[GROUP][2]; // boxes of the current group of listed buckets
+	// LDS is handed out in units of 1 280 bytes (160 KB / 128): 12 workgroups per CU -- the 3 waves per SIMD the registers
+	// allow -- fit only if each takes at most 10 units.  With 13 056 bytes (GROUP = 64) a CU held 11: measured 8.78 instead
+	// of 8.27 ms (12 800 and 12 928 bytes differ by exactly that step).
+	static_assert(SKT > 32 || TREEE_FRONT_CAP > TREEE_SBUF * 64 || sizeof(tile) + sizeof(buf) + sizeof(s_list) + sizeof(s_gbox) <= 10 * 1280,
+	              "the workgroup's LDS must stay within 10 allocation units of 1 280 bytes (12 workgroups per CU)");
 	const int lane = threadIdx.x;
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -854,8 +863,8 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 	ST(st_ph[7] = list_m);
 	if (!overflow) {
 		// ---- scan the listed buckets; the next bucket's load is in flight during each scan -------
-		for (uint32_t g = 0; g < list_m; g += 64) {
-			const uint32_t gcount = (list_m - g) < 64u ? (list_m - g) : 64u;
+		for (uint32_t g = 0; g < list_m; g += GROUP) {
+			const uint32_t gcount = (list_m - g) < GROUP ? (list_m - g) : GROUP;
 			// boxes of this group of listed buckets go to LDS (8 VGPRs less to carry through the scans)
 			if ((uint32_t)lane < gcount) {
 				const uint32_t my_leaf = s_list[g + lane];
