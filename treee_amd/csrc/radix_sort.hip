@@ -18,7 +18,10 @@
 namespace treee {
 
 constexpr int RS_BLOCK = 256;
-constexpr int RS_ITEMS = 16;
+#ifndef TREEE_RS_ITEMS
+#define TREEE_RS_ITEMS 16
+#endif
+constexpr int RS_ITEMS = TREEE_RS_ITEMS;
 constexpr int RS_TILE = RS_BLOCK * RS_ITEMS; // 4096 keys per workgroup
 
 // ---- Morton keys -------------------------------------------------------------------------
