@@ -40,8 +40,8 @@ BYTES = {"keys_sort_octree": 20 + 68 + 40, "keys_sort_octree_knn_structure": 20 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=15_000_000, help="points per GPU")
     ap.add_argument("--plot", type=float, default=PLOT, help="edge of the square tile in metres (632 with --points 150000000 keeps the density)")
     ap.add_argument("--halo", type=float, default=2.0)
@@ -115,6 +115,8 @@ def main():
     overlap = not args.no_overlap
     side = torch.cuda.Stream(dev) if overlap else None
     ctx2 = T.Context(dev, side) if overlap else None
+    if overlap:
+        ctx2.reserve(int(n * 1.15) * 24 + (32 << 20))  # node table, leaf ids, LOD lists and the scans' scratch of the side stream
     stages = Stage()
     halo = args.halo
     state = {}

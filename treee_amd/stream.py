@@ -71,6 +71,8 @@ class TileStream:
         # with kNN on, a tile's octree node table is completed on a side stream under the kNN structure's own build
         self.side = torch.cuda.Stream(self.device) if knn_k else None
         self.ctx2 = Context(self.device.index, self.side) if knn_k else None
+        if self.ctx2 is not None:
+            self.ctx2.reserve(int(max_points * 1.1) * 24 + (32 << 20))
         self.max_points, self.max_stride = int(max_points), int(max_stride)
         self.raw = [torch.empty((self.max_points * self.max_stride,), dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.xyz = torch.empty((self.max_points, 3), dtype=torch.float32, device=self.device)
