@@ -257,3 +257,17 @@ def test_laz_reader_fuzz(T):
             except (TreeeError, CorruptFile, NotImplementedError, MemoryError, OverflowError, ValueError) as e:
                 outcomes.add(type(e).__name__)
     assert {"ok", "TreeeError"} <= outcomes
+
+
+def test_laz_golden_fixture(T):
+    """tests/golden/laz_fmt3.npz (make_laz_golden.py): the committed LAZ image decodes to the committed records, and both
+    encoders still write exactly that image"""
+    from oracle import laz_encoder as E
+    from treee_amd.laz import laz_encode
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "laz_fmt3.npz"))
+    laz, las, rec = g["laz"].tobytes(), g["las"].tobytes(), g["records"]
+    got = []
+    T.Laz(laz).read(lambda ch: got.append(np.asarray(ch.slice).reshape(-1, rec.shape[1])))
+    assert [len(x) for x in got] == [250, 250, 100] and np.array_equal(np.concatenate(got), rec)
+    assert E.laz_bytes(las, chunk_size=250) == laz and laz_encode(las, chunk_size=250) == laz
