@@ -553,6 +553,51 @@ def test_full_size_15m_properties(T, oracle):
     check_knn_contract(pts, pts[:20_000], g_ent, g_cnt, r_ent, r_cnt)
 
 
+def test_full_size_15m_splat_bit_exact(T, oracle):
+    """BASELINE.json configs[1] at size: all 15 M points of the forest drawn into 1920 x 1080 with the reference's default
+    camera (treee/src/camera.rs:20-28) and the top-down view of SURVEY 8 D; depth and id bit for bit against the software
+    rasteriser (render/src/point_cloud.wgsl:37-80, depth state point_cloud.rs:76-82)."""
+    from treee_amd import synth
+
+    n = 15_000_000
+    d_pts, d_seg = synth.forest_cloud_torch(n, "cuda")
+    pts, seg = d_pts.cpu().numpy(), d_seg.cpu().numpy().astype(np.uint32)
+    w, h = 1920, 1080
+    proj = T.Camera3D(w / h).projection()
+    env = T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+    cloud, prop = T.PointCloud(d_pts), T.PointCloudProperty(d_seg)
+    for tf in (T.translation(0.0, 0.0, 100.0), T.rotation_x(-np.pi / 2) @ T.translation(0.0, 0.0, 300.0)):
+        view = T.view_from_transform(tf.astype(np.float32))
+        depth, ids = cloud.render(prop, view, proj, env, w, h)
+        rd, ri, _ = oracle.splat(pts, seg, view, proj, 0.1, 0, 0xFFFFFFFF, w, h)
+        assert np.array_equal(depth.cpu().numpy().view(np.uint32), rd.view(np.uint32))
+        assert np.array_equal(ids.cpu().numpy().view(np.uint32), ri)
+        assert int((rd < 1.0).sum()) > 50_000
+
+
+def test_config0_uniform_1m_knn_and_curve_vs_reference_kdtree(T, oracle):
+    """BASELINE.json configs[0]: 1 M uniform points quantised to 1 mm (SURVEY 8 D), k = 31, r = f32::MAX
+    (calculations.rs:278-279): every point's 31 neighbours against the restated KD-tree (counts, distance bits, indices
+    inside their tie groups) and its curve against the restated loop (calculations.rs:328-373)."""
+    import torch
+
+    from treee_amd import synth
+
+    pts = synth.uniform_cloud(1_000_000)
+    tree = T.KDTree.new(torch.from_numpy(pts).cuda())
+    dist, index, counts = tree.self_neighbors_dev(31)
+    curve = tree.curvature_dev(31).cpu().numpy()
+    r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts, 31, F32_MAX, threads=16)
+    g_ent = np.zeros((len(pts), 31), dtype=r_ent.dtype)
+    g_ent["distance"] = dist.cpu().numpy()
+    g_ent["index"] = index.cpu().numpy().view(np.uint32)
+    check_knn_contract(pts, pts, g_ent, counts.cpu().numpy(), r_ent, r_cnt)
+    ref = oracle.curvature(pts, 31, F32_MAX, threads=16)
+    ok = ~np.isnan(ref)
+    assert np.array_equal(np.isnan(curve), ~ok)
+    assert np.max(np.abs(curve[ok] - ref[ok])) < 1e-4
+
+
 def test_full_size_15m_segmented_properties(T, oracle):
     """configs[2] the way the reference holds a segmented cloud: one logical KD-tree per tree (2 501 segments)."""
     import torch
@@ -1280,6 +1325,34 @@ def test_segments_calculate_edge_cases(T, oracle):
     tall = np.array([[0, 0, 0], [0, 7000.0, 0]], np.float32)
     with pytest.raises(T.TreeeError):
         T.segments_calculate(tall, np.zeros(2, np.uint32), 1)  # more than 65 534 slices
+
+
+def test_segments_hull_appended_past_the_lds_copy(T, oracle):
+    """Tree::insert's append case -- the new point is outside the closing edge only, `splice(start+1..len, [point])`
+    (segmenting.rs:374-380) with e0 == 0 and s0 == m - 1 -- grows the hull by one like the insert-in-the-middle case.
+    Points of a slice that walk counter-clockwise along a convex arc are appended every time, so the hull reaches the
+    LDS capacity (128 per wave, 2 048 per workgroup) exactly through this branch; many such waves share one workgroup's
+    LDS, where a write past the copy would land in the neighbour's normals.  Plus 600 shuffled rings (the random
+    crossing of the capacity, 1 in 128 of which is an append)."""
+    parts, ids = [], []
+
+    def arc(cx, cz, r, count, y):
+        a = np.linspace(0.1, 5.4, count)
+        return np.stack([cx + r * np.cos(a), np.full(count, y), cz + r * np.sin(a)], 1)
+
+    for i in range(48):  # three workgroups of 16 waves: every wave crosses 128 by an append
+        parts.append(arc(10.0 * (i % 8), 10.0 * (i // 8), 3.0 + 0.01 * i, 200 + i, 1.02))
+        ids.append(i)
+    parts.append(arc(-40.0, -40.0, 50.0, 2300, 1.02))  # workgroup-per-slice kernel: crosses 2 048 by an append
+    ids.append(48)
+    rng = np.random.default_rng(77)
+    for i in range(600):
+        ang = rng.uniform(0, 2 * np.pi, 300)
+        parts.append(np.stack([100.0 + 8.0 * (i % 25) + 3.0 * np.cos(ang), np.full(300, 1.02), 8.0 * (i // 25) + 3.0 * np.sin(ang)], 1))
+        ids.append(49 + i)
+    pts = np.concatenate(parts).astype(np.float32)
+    seg = np.concatenate([np.full(len(p), s) for p, s in zip(parts, ids)]).astype(np.uint32)
+    _check_segments_against_oracle(T, oracle, pts, seg, 649, properties=False)
 
 
 def test_display_values_vs_oracle(T, oracle):

@@ -354,7 +354,17 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 			const float px = __shfl(p.x, f, 64), py = __shfl(p.y, f, 64);
 			// splice (segmenting.rs:374-380), cooperative.  Lanes move in lockstep: every lane reads its element before any
 			// lane writes, and the chunks run in the direction that never overwrites an unread source.
-			uint32_t new_m;
+			// (new size first: a hull that outgrows its LDS copy moves to the task's HBM slot BEFORE anything is written --
+			// the append case e0 == 0, s0 == m - 1 of the first branch grows the hull by one too)
+			const uint32_t new_m = e0 < s0 ? s0 - e0 + 2u : s0 + 2u + (m - e0);
+			if (new_m > cap) {
+				for (uint32_t c = 0; c < m; c += 64u)
+					if (c + lane < m) big[c + lane] = H[c + lane];
+				H = big;
+				N = big + (count + 2u);
+				cap = 0xFFFFFFFFu;
+				sync();
+			}
 			if (e0 < s0) { // H' = H[e0 ..= s0] + [point]
 				const uint32_t keep = s0 - e0 + 1u;
 				if (e0 > 0u)
@@ -367,18 +377,8 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 						sync();
 					}
 				if (lane == 0) H[keep] = P2{px, py};
-				new_m = keep + 1u;
 			} else { // H' = H[0 ..= s0] + [point] + H[e0 .. m)
 				const uint32_t tail = m - e0, dst = s0 + 2u;
-				new_m = dst + tail;
-				if (new_m > cap) { // the hull outgrows its LDS copy: continue in the task's HBM slot
-					for (uint32_t c = 0; c < m; c += 64u)
-						if (c + lane < m) big[c + lane] = H[c + lane];
-					H = big;
-					N = big + (count + 2u);
-					cap = 0xFFFFFFFFu;
-					sync();
-				}
 				if (dst < e0) { // shrink: shift the tail left, ascending
 					for (uint32_t c = 0; c < tail; c += 64u) {
 						const uint32_t k = c + lane;
@@ -561,6 +561,15 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS entri
 			__syncthreads();
 			const uint32_t s0 = s_se[0], e0 = s_se[1];
 			const P2 np = s_p;
+			// (new size first, as in slice_hull_wave: the move to HBM happens before any write of either branch)
+			if (m != 0 && (e0 < s0 ? s0 - e0 + 2u : s0 + 2u + (m - e0)) > cap) {
+				for (uint32_t c = 0; c < m; c += BIG_THREADS)
+					if (c + tid < m) big[c + tid] = H[c + tid];
+				__syncthreads();
+				H = big;
+				N = big + (count + 2u);
+				cap = NONE;
+			}
 			if (m == 0) {
 				if (tid == 0) {
 					H[0] = np;
@@ -575,14 +584,6 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS entri
 				m = keep + 1u;
 			} else { // H' = H[0 ..= s0] + [point] + H[e0 .. m)
 				const uint32_t tail = m - e0, dst = s0 + 2u;
-				if (dst + tail > cap) {
-					for (uint32_t c = 0; c < m; c += BIG_THREADS)
-						if (c + tid < m) big[c + tid] = H[c + tid];
-					__syncthreads();
-					H = big;
-					N = big + (count + 2u);
-					cap = NONE;
-				}
 				move(e0, dst, tail);
 				if (tid == 0) H[s0 + 1u] = np;
 				m = dst + tail;
