@@ -5,9 +5,13 @@
 //   nalgebra 0.33.0 (Cargo.lock:1562-1563): Point3 += Vector3, Point3 / f32 (component-wise
 //   true division), Matrix3::determinant (cofactor expansion along the first row);
 //   f32::powi(-3) = compiler-rt __powisf2 / LLVM ExpandPowI = 1 / (p * (p * p)).
-// acos/cos come from the host libm here; Rust uses the platform libm too, but the GPU uses
-// OCML, so `curve` is compared with a tolerance, never bit-exact.
+// acos / cos: Rust forwards them to the platform libm, HIP to OCML; both sides of the parity tests use the one
+// shared, correctly rounding definition of include/treee_f32_trig.h instead (checked against this host's libm in
+// tests/test_oracle.py: never more than 1 ulp apart, identical for > 99.7 % of the arguments), so that `curve` is
+// compared bit for bit wherever the neighbour lists agree.
 #include "treee_oracle.h"
+
+#include "../include/treee_f32_trig.h"
 
 #include <cmath>
 #include <thread>
@@ -50,9 +54,9 @@ void fast_eigenvalues(const float mat[3][3], float out[3]) {
 	else if (r >= 1.0f)
 		phi = 0.0f;
 	else
-		phi = std::acos(r) / 3.0f;
-	float eig_1 = q + 2.0f * p * std::cos(phi);
-	float eig_3 = q + 2.0f * p * std::cos(phi + (2.0f * PI / 3.0f));
+		phi = treee_acos_f32(r) / 3.0f;
+	float eig_1 = q + 2.0f * p * treee_cos_f32(phi);
+	float eig_3 = q + 2.0f * p * treee_cos_f32(phi + (2.0f * PI / 3.0f));
 	float eig_2 = 3.0f * q - eig_1 - eig_3;
 	out[0] = eig_1;
 	out[1] = eig_2;
@@ -99,6 +103,39 @@ void orc_fast_eigenvalues(const float m[9], float out[3]) {
 
 float orc_curve_from_neighbors(const float *xyz, const orc_entry *nb, uint64_t count) {
 	return curve_from(xyz, nb, count);
+}
+
+// the loop body of calculations.rs:342-368 over GIVEN neighbour lists (u32 index[nq][k], the first counts[i] of a row
+// are valid, summed in the order given): separates the arithmetic from the neighbour search when an implementation's
+// lists differ from the KD-tree's inside distance ties
+void orc_curve_from_lists(const float *xyz, const uint32_t *index, const uint32_t *counts, uint64_t nq, uint64_t k,
+                          float *curve_out, int threads) {
+	auto work = [&](uint64_t lo, uint64_t hi) {
+		std::vector<orc_entry> loc(k);
+		for (uint64_t i = lo; i < hi; ++i) {
+			const uint64_t c = counts ? counts[i] : k;
+			for (uint64_t j = 0; j < c; ++j) loc[j].index = index[i * k + j];
+			curve_out[i] = curve_from(xyz, loc.data(), c);
+		}
+	};
+	if (threads <= 1) return work(0, nq);
+	std::vector<std::thread> pool;
+	const uint64_t per = (nq + threads - 1) / threads;
+	for (int th = 0; th < threads; ++th) {
+		const uint64_t lo = per * th < nq ? per * th : nq, hi = lo + per < nq ? lo + per : nq;
+		if (lo < hi) pool.emplace_back(work, lo, hi);
+	}
+	for (auto &th : pool) th.join();
+}
+
+// the two shared functions themselves, and this host's libm beside them (tests)
+void orc_trig_f32(const float *x, uint64_t n, float *acos_out, float *cos_out, float *libm_acos_out, float *libm_cos_out) {
+	for (uint64_t i = 0; i < n; ++i) {
+		acos_out[i] = treee_acos_f32(x[i]);
+		cos_out[i] = treee_cos_f32(x[i]);
+		libm_acos_out[i] = std::acos(x[i]);
+		libm_cos_out[i] = std::cos(x[i]);
+	}
 }
 
 void orc_curvature(const float *xyz, uint64_t n, uint64_t k, float max_distance, float *curve_out,

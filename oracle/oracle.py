@@ -74,6 +74,8 @@ def lib():
         L.orc_curve_from_neighbors.restype = f32
         L.orc_curve_from_neighbors.argtypes = [vp, vp, u64]
         L.orc_curvature.argtypes = [vp, u64, u64, f32, vp, i32]
+        L.orc_curve_from_lists.argtypes = [vp, vp, vp, u64, u64, vp, i32]
+        L.orc_trig_f32.argtypes = [vp, u64, vp, vp, vp, vp]
         L.orc_map_to_u32.restype = u32
         L.orc_map_to_u32.argtypes = [f32]
         L.orc_decode_las_records.argtypes = [vp, u64, u32, vp, vp, vp, vp]
@@ -180,6 +182,25 @@ def curve_from_neighbors(points, entries):
     points = _f32(points, 3)
     entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
     return float(lib().orc_curve_from_neighbors(_p(points), _p(entries), len(entries)))
+
+
+def curve_from_lists(points, index, counts=None, threads=1):
+    """calculations.rs:342-368 over given neighbour lists (index [nq, k] u32, first counts[i] valid), summed in list order"""
+    points = _f32(points, 3)
+    index = np.ascontiguousarray(index, dtype=np.uint32)
+    nq, k = index.shape
+    cnt = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint32)
+    out = np.zeros(nq, np.float32)
+    lib().orc_curve_from_lists(_p(points), _p(index), None if cnt is None else _p(cnt), nq, k, _p(out), threads)
+    return out
+
+
+def trig_f32(x):
+    """(shared acos, shared cos, libm acosf, libm cosf) of the f32 array x (include/treee_f32_trig.h)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    outs = [np.zeros(len(x), np.float32) for _ in range(4)]
+    lib().orc_trig_f32(_p(x), len(x), *[_p(o) for o in outs])
+    return outs
 
 
 def curvature(points, k=31, max_distance=np.finfo(np.float32).max, threads=1):

@@ -64,6 +64,11 @@ uint64_t orc_brute_k_nearest(const float *xyz, uint64_t n, const float q[3], orc
 void orc_fast_eigenvalues(const float m[9] /* row-major 3x3 */, float out[3]);
 /* curve from an explicit neighbour list (indices into xyz) */
 float orc_curve_from_neighbors(const float *xyz, const orc_entry *nb, uint64_t count);
+/* the same for nq given lists (u32 index[nq][k], counts[nq] or NULL = k), summed in the order given */
+void orc_curve_from_lists(const float *xyz, const uint32_t *index, const uint32_t *counts, uint64_t nq, uint64_t k,
+                          float *curve_out, int threads);
+/* include/treee_f32_trig.h (the shared acos / cos) beside this host's libm */
+void orc_trig_f32(const float *x, uint64_t n, float *acos_out, float *cos_out, float *libm_acos_out, float *libm_cos_out);
 /* full loop: tree over xyz[n], k neighbours (k=31 in the reference), radius */
 void orc_curvature(const float *xyz, uint64_t n, uint64_t k, float max_distance, float *curve_out,
                    int threads);

@@ -1,6 +1,6 @@
 """GPU parity tests proper: every call goes through the C ABI (libtreee_hip.so) and is compared
 with the CPU oracle on the same seeded inputs.  Bit-exact for integer / index / distance
-work; `curve` within 1e-5 (acos/cos: libm vs OCML)."""
+work and for `curve` wherever the neighbour lists agree (acos / cos: include/treee_f32_trig.h on both sides)."""
 import os
 
 import numpy as np
@@ -188,17 +188,61 @@ def test_knn_radius_and_empty_vs_reference(T, oracle):
 
 
 # ---------------------------------------------------------------- A5 curvature
+def same_f32(a, b):
+    """bit-identical f32 arrays; NaN matches NaN (0/0 has the sign bit set on x86 and clear on gfx950)"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    na, nb = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb]))
+
+
+def check_curve_against_the_restated_loop(T, oracle, pts, k=31, threads=8, tree=None):
+    """`curve` of every point against calculations.rs:328-373 restated, with the two causes of a difference kept apart:
+    (1) the arithmetic -- the restated loop body run over the library's OWN neighbour lists must give the library's
+        curve bit for bit, for every point (acos / cos are the shared include/treee_f32_trig.h on both sides);
+    (2) the neighbour lists -- wherever the library's list equals the restated KD-tree's, `curve` therefore equals the
+        reference's bit for bit; the rows where it does not are rows with a distance tie: inside the list
+        (same set, another order: another f32 summation order) or at its edge (the k-th and (k+1)-th neighbour are
+        equally far: another member).  Returns the statistics of those rows."""
+    import torch
+
+    d_pts = torch.from_numpy(pts).cuda()
+    tree = tree or T.KDTree.new(d_pts)
+    dist, index, counts = tree.self_neighbors_dev(k)
+    curve = tree.curvature_dev(k).cpu().numpy()
+    dist, index, counts = dist.cpu().numpy(), index.cpu().numpy().view(np.uint32), counts.cpu().numpy().astype(np.uint32)
+    own = oracle.curve_from_lists(pts, index, counts, threads=threads)
+    assert same_f32(curve, own), "the curvature arithmetic differs from the restated loop on identical neighbour lists"
+    r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts, k, F32_MAX, threads=threads)
+    ref = oracle.curvature(pts, k, F32_MAX, threads=threads)
+    assert np.array_equal(counts, r_cnt.astype(np.uint32))
+    assert np.array_equal(dist.view(np.uint32), r_ent["distance"].view(np.uint32))
+    r_idx = r_ent["index"].astype(np.uint32)
+    same_list = (index == r_idx).all(1)
+    assert same_f32(curve[same_list], ref[same_list])
+    same_set = (np.sort(index, 1) == np.sort(r_idx, 1)).all(1)
+    tie_inside = (dist[:, 1:] == dist[:, :-1]).any(1)
+    assert not (~same_list & ~tie_inside & same_set).any(), "lists differ without a distance tie"
+    err = np.abs(curve.astype(np.float64) - ref.astype(np.float64))
+    err[np.isnan(err)] = 0.0
+    assert np.array_equal(np.isnan(curve), np.isnan(ref))
+
+    def stat(m):
+        return {"rows": int(m.sum()), "max": float(err[m].max()) if m.any() else 0.0,
+                "p9999": float(np.quantile(err[m], 0.9999)) if m.any() else 0.0}
+
+    return {"n": len(pts), "identical_lists": stat(same_list), "tie_inside_same_set": stat(~same_list & same_set),
+            "tie_at_the_edge_other_member": stat(~same_set), "rows_with_a_tie_inside": int(tie_inside.sum())}
+
+
 def test_curvature_vs_oracle(T, oracle):
     from treee_amd import synth
 
     pts, _ = synth.forest_cloud(40_000, plot=12.0)
-    ref = oracle.curvature(pts, 31, F32_MAX, threads=8)
-    got = T.curvature(pts, 31, F32_MAX)
-    nan = np.isnan(ref)
-    assert np.array_equal(np.isnan(got), nan)
-    # exact-tie neighbourhoods may sum in another order (H2) and acos/cos differ (H3)
-    assert np.max(np.abs(got[~nan] - ref[~nan])) < 1e-4
-    assert np.mean(np.abs(got[~nan] - ref[~nan]) < 1e-5) > 0.999
+    st = check_curve_against_the_restated_loop(T, oracle, pts)
+    assert st["identical_lists"]["max"] == 0.0
+    assert st["tie_inside_same_set"]["max"] < 1e-4  # another summation order of the same 31 points
+    got = T.curvature(pts, 31, F32_MAX)  # host-pointer entry
+    assert same_f32(got, T.KDTree.new(pts).curvature_dev(31).cpu().numpy())
 
 
 def test_curvature_of_own_points_only(T):
@@ -221,14 +265,42 @@ def test_curvature_of_own_points_only(T):
         assert torch.equal(a[:n_own].view(torch.int32), b.view(torch.int32))
 
 
-def test_curvature_tie_free_cloud_tight_tolerance(T, oracle):
+def test_curvature_tie_free_cloud_bit_exact(T, oracle):
     rng = np.random.default_rng(9)
     pts = rng.random((20_000, 3)).astype(np.float32) * np.float32(25)  # full-mantissa: no distance ties
     ref = oracle.curvature(pts, 31, F32_MAX, threads=8)
     got = T.curvature(pts, 31, F32_MAX)
-    assert np.max(np.abs(got - ref)) < 1e-5
+    assert same_f32(got, ref)  # calculations.rs:328-373 + :467-498 to the last bit
+    st = check_curve_against_the_restated_loop(T, oracle, pts)
+    assert st["identical_lists"]["rows"] == len(pts)
     u = T.map_to_u32_dev(__import__("torch").from_numpy(got).cuda()).cpu().numpy().view(np.uint32)
     assert u.tolist()[:50] == [oracle.map_to_u32(v) for v in got[:50]]
+
+
+def test_curve_error_separated_by_cause_at_the_benchmark_density(T, oracle):
+    """on a forest patch at the 15 M configuration's density (375 points / m^2, 1 mm quantised) report
+    (a) how many queries have a distance tie inside their 31 or at their edge, (b) max and 99.99-percentile |d curve|
+    for the tie-free and the tied queries separately.  Tie-free rows are bit-exact by the check above; the tolerance that
+    remains belongs to the tied rows and is set from what is measured here."""
+    import json
+
+    from treee_amd import synth
+
+    n = 1_000_000
+    pts, _ = synth.forest_cloud(n, plot=200.0 * (n / 15_000_000) ** 0.5)
+    st = check_curve_against_the_restated_loop(T, oracle, pts, threads=16)
+    tree = T.KDTree.new(__import__("torch").from_numpy(pts).cuda())
+    d32 = tree.self_neighbors_dev(32)[0].cpu().numpy()
+    st["rows_with_a_tie_at_the_edge"] = int((d32[:, 30] == d32[:, 31]).sum())
+    print("curve error by cause:", json.dumps(st))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        json.dump(st, open("gpurun_out/curve_error_by_cause.json", "w"), indent=1)
+    except OSError:
+        pass
+    assert st["identical_lists"]["max"] == 0.0 and st["identical_lists"]["rows"] > 0.5 * n
+    assert st["tie_inside_same_set"]["max"] < 2e-5
+    assert st["tie_at_the_edge_other_member"]["rows"] <= st["rows_with_a_tie_at_the_edge"]
 
 
 # ---------------------------------------------------------------- A5 as the reference calls it: one tree per segment
@@ -577,25 +649,14 @@ def test_full_size_15m_splat_bit_exact(T, oracle):
 
 def test_config0_uniform_1m_knn_and_curve_vs_reference_kdtree(T, oracle):
     """BASELINE.json configs[0]: 1 M uniform points quantised to 1 mm (SURVEY 8 D), k = 31, r = f32::MAX
-    (calculations.rs:278-279): every point's 31 neighbours against the restated KD-tree (counts, distance bits, indices
-    inside their tie groups) and its curve against the restated loop (calculations.rs:328-373)."""
-    import torch
-
+    (calculations.rs:278-279): every point's 31 neighbours against the restated KD-tree (counts and distance bits) and its
+    curve against the restated loop (calculations.rs:328-373): bit for bit wherever the lists agree."""
     from treee_amd import synth
 
     pts = synth.uniform_cloud(1_000_000)
-    tree = T.KDTree.new(torch.from_numpy(pts).cuda())
-    dist, index, counts = tree.self_neighbors_dev(31)
-    curve = tree.curvature_dev(31).cpu().numpy()
-    r_ent, r_cnt = oracle.KDTree(pts).k_nearest_batch(pts, 31, F32_MAX, threads=16)
-    g_ent = np.zeros((len(pts), 31), dtype=r_ent.dtype)
-    g_ent["distance"] = dist.cpu().numpy()
-    g_ent["index"] = index.cpu().numpy().view(np.uint32)
-    check_knn_contract(pts, pts, g_ent, counts.cpu().numpy(), r_ent, r_cnt)
-    ref = oracle.curvature(pts, 31, F32_MAX, threads=16)
-    ok = ~np.isnan(ref)
-    assert np.array_equal(np.isnan(curve), ~ok)
-    assert np.max(np.abs(curve[ok] - ref[ok])) < 1e-4
+    st = check_curve_against_the_restated_loop(T, oracle, pts, threads=16)
+    assert st["identical_lists"]["max"] == 0.0 and st["identical_lists"]["rows"] > 900_000
+    assert st["tie_inside_same_set"]["max"] < 1e-4
 
 
 def test_full_size_15m_segmented_properties(T, oracle):

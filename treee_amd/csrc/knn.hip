@@ -19,6 +19,7 @@
 // Morton cell (hilbert30, common.h), the order the structure's buckets are cut in.  Distances and counts are
 // bit-identical to the reference; indices are identical whenever distances are distinct.
 #include "common.h"
+#include "../../include/treee_f32_trig.h"
 
 #include <cstdlib>
 
@@ -190,9 +191,9 @@ __device__ __forceinline__ void fast_eigenvalues(const float mat[3][3], float ou
 	else if (r >= 1.0f)
 		phi = 0.0f;
 	else
-		phi = acosf(r) / 3.0f;
-	const float eig1 = q + 2.0f * p * cosf(phi);
-	const float eig3 = q + 2.0f * p * cosf(phi + (2.0f * PI / 3.0f));
+		phi = treee_acos_f32(r) / 3.0f; // (the shared last-bit definition of f32::acos / cos: include/treee_f32_trig.h)
+	const float eig1 = q + 2.0f * p * treee_cos_f32(phi);
+	const float eig3 = q + 2.0f * p * treee_cos_f32(phi + (2.0f * PI / 3.0f));
 	const float eig2 = 3.0f * q - eig1 - eig3;
 	out[0] = eig1;
 	out[1] = eig2;
