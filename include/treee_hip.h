@@ -157,7 +157,7 @@ int32_t treee_map_to_u32_dev(treee_ctx *ctx, const float *d_in, uint64_t n, uint
  * *n_segments_out = largest id + 1.  The reference's run is random (thread_rng shuffle, RandomState map order, random
  * ids) and its Voronoi cells come from a third-party crate absent from the snapshot: this is the deterministic variant
  * SURVEY.md F1 prescribes -- seeded shuffle, ordered maps, ids 1, 2, 3 ... in creation order, cells restated -- with
- * every departure marked in csrc/segmenting.hip.  It runs on the host: the algorithm is serial per slice (each point
+ * every departure marked in csrc/segmenting.cpp.  It runs on the host: the algorithm is serial per slice (each point
  * is tested against the hulls the earlier points built), the reference keeps it on CPU workers too.
  * max_distance: the reference's slider value (default 0.75, segmenting.rs:16). */
 int32_t treee_segment_slices(const float *xyz_aos, uint64_t n, const float bbox_min_xz[2], const float bbox_max_xz[2],
@@ -275,7 +275,7 @@ int32_t treee_decode_las_records_dev(treee_ctx *ctx, const uint8_t *d_rec, uint6
 /* LAZ sources (laz.rs:77-94,146-160).  The reference hands these to the crate `laz` 0.9.2 (not in the snapshot); this
  * library restates the published LASzip format for LAS 1.0-1.3 files: pointwise chunked compressor, items POINT10 /
  * GPSTIME11 / RGB12 / BYTE of version 2.  Host code on host threads, as in the reference.  PARITY UNPINNED: no LAZ file
- * or tool exists where this was built (csrc/laz_codec.hip).
+ * or tool exists where this was built (csrc/laz_codec.cpp).
  * treee_laz_chunk_table: `laz::laszip::ChunkTable::read_from` -- byte and point count of every chunk (the first chunk
  * starts at offset_to_point_data + 8); chunk_size = the LAZ record's (0xFFFFFFFF: variable); point counts are clipped to
  * total_points like laz.rs:88-89.  Call with byte_counts_out == NULL to learn *n_chunks_out. */

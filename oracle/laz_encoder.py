@@ -1,4 +1,4 @@
-"""CPU ORACLE (test infrastructure): a LASzip ENCODER written independently of treee_amd/csrc/laz_codec.hip, from the same
+"""CPU ORACLE (test infrastructure): a LASzip ENCODER written independently of treee_amd/csrc/laz_codec.cpp, from the same
 published format (M. Isenburg, "LASzip: lossless compression of LiDAR data", PE&RS 79(2), 2013; the range coder of A. Said's
 FastAC that LASzip adopts): pointwise chunked compressor, items POINT10 / GPSTIME11 / RGB12 / BYTE, version 2.  It exists so
 that the library's decoder can be checked on something: the reference hands LAZ to the crate `laz` 0.9.2, which is not in

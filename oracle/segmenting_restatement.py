@@ -1,7 +1,7 @@
 """CPU ORACLE (test infrastructure): an independent pure-Python restatement of the Segmenting phase,
 treee/src/segmenting.rs:110-235 (segmentation), :242-396 (Tree), :419-524 (TreeSet), :526-545 (centroid), in the
 deterministic variant SURVEY.md section 8 F1 prescribes.  Written from the cited Rust lines, not from the C++ in
-treee_amd/csrc/segmenting.hip; it shares only the four documented rules that replace the reference's randomness:
+treee_amd/csrc/segmenting.cpp; it shares only the four documented rules that replace the reference's randomness:
   D1 shuffle = Fisher-Yates from the end with SplitMix64(seed ^ (0xD1B54A32D192ED03 * (key - min_key + 1)))
   D2 HashMap<u32, Centroid> iterated in ascending key order
   D3 new ids 1, 2, 3 ... in creation order (0 = DELETED_INDEX)

@@ -13,7 +13,7 @@ cd $repo/treee_amd/csrc
 for f in context radix_sort octree knn splat ingest shard calculations; do cp build/$f.o $out/; done
 for f in laz_codec segmenting; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
-    -fsanitize=address,undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -c $f.hip -o $out/$f.o
+    -fsanitize=address,undefined -fno-gpu-sanitize -fno-sanitize-recover=undefined -x hip -c $f.cpp -o $out/$f.o
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -o $out/libtreee_hip_san.so $out/*.o -Wl,-rpath,/opt/rocm/lib
 asan=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)

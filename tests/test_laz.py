@@ -1,5 +1,5 @@
 """LAZ sources (laz.rs:77-94,146-160).  The reference leaves the format to the crate `laz` 0.9.2 (absent from the snapshot) and
-no LAZ file or tool exists here, so the library's decoder (treee_amd/csrc/laz_codec.hip, host code) is checked against an
+no LAZ file or tool exists here, so the library's decoder (treee_amd/csrc/laz_codec.cpp, host code) is checked against an
 encoder written independently from the same published format (oracle/laz_encoder.py): parity with real LASzip files is
 UNPINNED.  CPU tests: the decoder runs on host threads."""
 import os

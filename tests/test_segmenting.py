@@ -1,5 +1,5 @@
 """CPU-only: the Segmenting phase -- host code in libtreee_hip.so, as in the reference.
-The library's C++ (treee_amd/csrc/segmenting.hip) against the independent pure-Python restatement of the cited Rust lines
+The library's C++ (treee_amd/csrc/segmenting.cpp) against the independent pure-Python restatement of the cited Rust lines
 (oracle/segmenting_restatement.py), hand-traced cases, and properties the algorithm must have whatever the shuffle."""
 import numpy as np
 import pytest

@@ -1,4 +1,4 @@
-// context.hip -- error state, treee_ctx (stream + workspace arena), default context.
+// context.cpp -- error state, treee_ctx (stream + workspace arena), default context.
 #include "common.h"
 
 #include <mutex>

@@ -1,4 +1,4 @@
-// laz_codec.hip -- LASzip point decompression (host code; like segmenting.hip it is in the library because the reference
+// laz_codec.cpp -- LASzip point decompression (host code; like segmenting.cpp it is in the library because the reference
 // does this work on host threads, treee/src/laz.rs:130-180: one chunk per rayon task, decompress_many, then next_point).
 //
 // The reference delegates it to the third-party crate `laz` 0.9.2 (Cargo.lock:1393-1394; call sites laz.rs:1-8,77-94,146-160),

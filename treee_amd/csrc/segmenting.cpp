@@ -1,4 +1,4 @@
-// segmenting.hip -- the slice segmentation of the reference, HOST code like the reference's:
+// segmenting.cpp -- the slice segmentation of the reference, HOST code like the reference's:
 //   segmentation       treee/src/segmenting.rs:110-235   slices top-down, centroid hand-off, Voronoi cells, assignment
 //   Tree               treee/src/segmenting.rs:242-396   convex area: new, from_points, distance, outside_bounds, contains, insert
 //   TreeSet            treee/src/segmenting.rs:419-524   new, add_point, filter_trees, tree_positions

@@ -3,7 +3,7 @@ treee/src/loading.rs:91-115.
 
 LAZ sources: the reference hands decompression to the third-party crate `laz` 0.9.2 (not in the snapshot).  The library
 restates the published LASzip format for LAS 1.0-1.3 files (pointwise chunked, items POINT10 / GPSTIME11 / RGB12 / BYTE,
-version 2: treee_amd/csrc/laz_codec.hip, host threads like the reference's rayon tasks); layered LAS 1.4 items raise
+version 2: treee_amd/csrc/laz_codec.cpp, host threads like the reference's rayon tasks); layered LAS 1.4 items raise
 NotImplementedError.  Parity unpinned: no LAZ file or tool exists in the build container."""
 import struct
 

@@ -1,7 +1,7 @@
 """Mirror of the Segmenting phase (treee/src/segmenting.rs): `segmentation` (:110-235) over the y-slices of a loaded
 cloud -> one segment id per point, the `segment: Vec<u32>` of `Event::PointCloud` (treee/src/program.rs:18-22) that the
 Calculations phase, the per-segment kNN and the splat consume.  Host code in the library, as in the reference
-(csrc/segmenting.hip lists the four places where the reference's randomness is replaced by fixed rules)."""
+(csrc/segmenting.cpp lists the four places where the reference's randomness is replaced by fixed rules)."""
 import ctypes as C
 
 import numpy as np
