@@ -299,7 +299,7 @@ def test_curve_error_separated_by_cause_at_the_benchmark_density(T, oracle):
     except OSError:
         pass
     assert st["identical_lists"]["max"] == 0.0 and st["identical_lists"]["rows"] > 0.5 * n
-    assert st["tie_inside_same_set"]["max"] < 2e-5
+    assert st["tie_inside_same_set"]["max"] < 5e-6  # measured 6.6e-7 (profiles/r03_curve_error_by_cause.json)
     assert st["tie_at_the_edge_other_member"]["rows"] <= st["rows_with_a_tie_at_the_edge"]
 
 
