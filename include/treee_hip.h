@@ -317,6 +317,134 @@ int32_t treee_slice_bin_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, 
 int32_t treee_select_xz_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, const float keep_box[4],
                             const float drop_box[4], float *d_out_xyz, uint64_t cap, uint32_t *d_count_out);
 
+
+/* ---- E: many GPUs -- communicator ----------------------------------------------------------------------------------
+ * One process per GPU.  The entry points below that take a treee_comm run the same code on every rank and talk to the
+ * other ranks through it.  Two transports:
+ *   - RCCL (treee_comm_create_rccl / treee_comm_wrap_rccl): collectives are enqueued on the context's stream, payloads
+ *     stay in HBM and travel over xGMI.  librccl.so is opened at run time (dlopen; the copy the process already holds, else
+ *     TREEE_RCCL_LIB, else /opt/rocm/lib).  UNVERIFIED ON MULTI-GPU HARDWARE: the development pool has one-GPU boxes, the
+ *     RCCL transport is exercised with a one-rank communicator only.
+ *   - host callbacks (treee_comm_create_host): the caller moves host buffers with whatever it has (MPI, sockets, a test's
+ *     torch.distributed/gloo group); the library stages device data through host memory.  This is what the two-rank
+ *     rehearsals on one GPU and hosts without RCCL use.
+ * No reference counterpart (the reference is one process); SURVEY.md section 8 row E. */
+typedef struct treee_comm treee_comm;
+typedef struct {
+	void *user;
+	/* every rank contributes `bytes` bytes; recv holds world * bytes in rank order */
+	int32_t (*all_gather)(void *user, const void *send, void *recv, uint64_t bytes);
+	/* rank r receives send[send_off[r] ..+ send_bytes[r]) of every rank s into recv[recv_off[s] ..+ recv_bytes[s]) */
+	int32_t (*all_to_all_v)(void *user, const void *send, const uint64_t *send_off, const uint64_t *send_bytes, void *recv,
+	                        const uint64_t *recv_off, const uint64_t *recv_bytes);
+	/* element-wise minimum over all ranks, in place */
+	int32_t (*all_reduce_min_u64)(void *user, uint64_t *buf, uint64_t count);
+} treee_comm_host_ops;
+int32_t treee_comm_create_host(const treee_comm_host_ops *ops, int32_t rank, int32_t world, treee_comm **out);
+/* ncclGetUniqueId on one rank; the caller brings the 128 bytes to the others */
+int32_t treee_rccl_unique_id(uint8_t id_out[128]);
+/* ncclCommInitRank on `device` (collective: every rank calls it) */
+int32_t treee_comm_create_rccl(const uint8_t unique_id[128], int32_t rank, int32_t world, int32_t device, treee_comm **out);
+/* an ncclComm_t the caller already owns (not destroyed by treee_comm_destroy) */
+int32_t treee_comm_wrap_rccl(void *nccl_comm, int32_t rank, int32_t world, treee_comm **out);
+int32_t treee_comm_destroy(treee_comm *c);
+int32_t treee_comm_info(const treee_comm *c, int32_t *rank_out, int32_t *world_out, int32_t *is_rccl_out);
+
+/* ---- E: the sharded octree -------------------------------------------------------------------------------------------
+ * The octree of the WHOLE cloud (the concatenation of every rank's input, rank order; global index of a point = points on
+ * lower ranks + its position) held in pieces: node for node, field for field the table treee_sort_build gives for that
+ * cloud with the same cube (tests assemble the pieces and compare bit for bit).
+ *   - all ranks use one cube (given, or the union's cube by the rule of treee_sort_build);
+ *   - the cube's level-`top_level` Morton cells (8^top_level of them) are dealt to the ranks in key order, balanced by
+ *     point count: rank r owns one contiguous key range = one contiguous range of the global sorted order;
+ *   - one all-to-all moves every point to the owner of its cell (nothing moves when the input already is so tiled);
+ *   - levels < top_level (the "top") are the same on every rank, computed from the all-gathered cell counts; a node of
+ *     level >= top_level lives on the rank that owns its cell, with GLOBAL first / parent / first_child / lod_first;
+ *     global index of the j-th own node of level l = own_node_first[l] + j.
+ * Collectives: all-gather of cell counts (4 * 8^top_level B per rank), all-to-all of 16-B records, all-gather of 22 words. */
+#define TREEE_SHARD_LEVELS 11
+typedef struct treee_shard_plan treee_shard_plan;
+typedef struct {
+	uint64_t n_total;       /* points of the whole cloud */
+	uint32_t world, top_level;
+	uint32_t n_top_nodes;   /* nodes of levels < top_level (replicated) */
+	uint32_t n_top_lod;     /* their LOD entries */
+	uint32_t n_level_nodes; /* nodes of level top_level, all ranks */
+	uint32_t leaf_cap, lod_cap;
+} treee_shard_plan_info;
+typedef struct {
+	uint32_t cell_begin, cell_end; /* owned level-top_level cells */
+	uint64_t first, count;         /* owned range of the global sorted order */
+	uint64_t index_base;           /* global index of the rank's input point 0 */
+	uint32_t level_node_first, level_node_count; /* owned nodes of level top_level: position inside that level, count */
+} treee_shard_plan_rank;
+typedef struct {
+	uint64_t n_nodes_total, n_lod_total;
+	uint32_t node_begin[TREEE_SHARD_LEVELS];     /* global index of the level's first node */
+	uint32_t own_node_first[TREEE_SHARD_LEVELS]; /* global index of the rank's first node of the level */
+	uint32_t own_node_count[TREEE_SHARD_LEVELS];
+	uint32_t lod_begin[TREEE_SHARD_LEVELS], own_lod_first[TREEE_SHARD_LEVELS], own_lod_count[TREEE_SHARD_LEVELS];
+} treee_shard_levels;
+/* Pure host arithmetic (no GPU, no communication; every rank computes the same plan from the same counts).
+ * cell_counts[world][8^top_level]: points of every rank's INPUT per cell.  top_level in [1, 6]. */
+int32_t treee_shard_plan_create(const uint32_t *cell_counts, int32_t world, uint32_t top_level, uint32_t leaf_cap, uint32_t lod_cap,
+                                treee_shard_plan **out);
+int32_t treee_shard_plan_free(treee_shard_plan *p);
+int32_t treee_shard_plan_info_get(const treee_shard_plan *p, treee_shard_plan_info *info);
+int32_t treee_shard_plan_rank_get(const treee_shard_plan *p, int32_t rank, treee_shard_plan_rank *out);
+/* the replicated top: nodes_out[n_top_nodes] (global fields, lod_first set) */
+int32_t treee_shard_plan_top_nodes(const treee_shard_plan *p, treee_octree_node *nodes_out);
+/* the rank's nodes of level top_level as the roots of its local forest: `first` relative to the rank's range, parent
+ * global (a top node), first_child / child_mask / lod_first still unset */
+int32_t treee_shard_plan_level_nodes(const treee_shard_plan *p, int32_t rank, treee_octree_node *nodes_out);
+/* what rank `rank` sends: positions [send_first[r], send_first[r] + send_count[r]) of its locally sorted input go to rank
+ * r; recv_count[s] points arrive from rank s */
+int32_t treee_shard_plan_exchange(const treee_shard_plan *p, int32_t rank, uint64_t *send_first, uint64_t *send_count, uint64_t *recv_count);
+/* after the local builds: level_counts / lod_counts [world][TREEE_SHARD_LEVELS] = every rank's own nodes / LOD entries
+ * per level (all-gathered) -> the global numbering */
+int32_t treee_shard_plan_levels(const treee_shard_plan *p, const uint32_t *level_counts, const uint32_t *lod_counts, int32_t rank,
+                                treee_shard_levels *out);
+
+/* The cube of the union of all ranks' points by the rule of treee_sort_build (min corner, largest extent). */
+int32_t treee_shard_cube_dev(treee_ctx *ctx, treee_comm *comm, const float *d_xyz_aos, uint64_t n, float corner_out[3], float *size_out);
+/* Collective.  size <= 0: the cube is computed with treee_shard_cube_dev.  top_level 0 -> 5.  The handle is a
+ * treee_octree whose arrays are the rank's piece: KEYS / PERM (global indices) / SORTED_XYZ (.w = global index) / LEAF
+ * (global node index) over the owned range, NODES = own nodes of levels >= top_level in level order, LOD = their
+ * entries (global sorted positions), TOP_NODES / TOP_LOD = the replicated top.  treee_octree_info_get reports the own
+ * counts; treee_knn_from_octree_dev refuses such a handle. */
+int32_t treee_shard_octree_build_dev(treee_ctx *ctx, treee_comm *comm, const float *d_xyz_aos, uint64_t n, const float corner[3],
+                                     float size, uint32_t leaf_cap, uint32_t lod_cap, uint32_t top_level, treee_octree **out);
+int32_t treee_shard_octree_info_get(const treee_octree *o, treee_shard_plan_info *info, treee_shard_plan_rank *rank,
+                                    treee_shard_levels *levels);
+enum { TREEE_OCT_TOP_NODES = 6, TREEE_OCT_TOP_LOD = 7 };
+
+/* ---- E: ghost points and the frame across ranks ---------------------------------------------------------------------
+ * x/z tiles (treee_select_xz_dev above).  tile_box = {x0, x1, z0, z1} of this rank; shared_faces bit 0..3 = the x-, x+,
+ * z-, z+ face touches another tile.  d_cloud holds the rank's own n_own points first and has room for n_own + ghost_cap
+ * points: the ghosts (points of other ranks inside the tile dilated by halo) are written behind the own points in
+ * (rank, input order).  ONE all-gather of fixed-capacity blocks (send_cap points per rank; row 0 of a block carries the
+ * sender's count).  *n_ghost_out = ghosts found, *most_sent_out = the largest contribution: when it exceeds send_cap or
+ * n_ghost exceeds ghost_cap every rank sees the same numbers and the caller repeats with larger capacities (status
+ * TREEE_OK either way).  Synchronises once (the two counts). */
+int32_t treee_shard_exchange_ghosts_dev(treee_ctx *ctx, treee_comm *comm, float *d_cloud, uint64_t n_own, const float tile_box[4],
+                                        uint32_t shared_faces, float halo, uint64_t send_cap, uint64_t ghost_cap, uint64_t *n_ghost_out,
+                                        uint64_t *most_sent_out);
+/* element-wise MIN of the packed (depth_bits << 32 | index) frames of all ranks, in place (treee_splat_dev with
+ * index_base = points on lower ranks): what one GPU drawing everything would hold */
+int32_t treee_frame_reduce_min_dev(treee_ctx *ctx, treee_comm *comm, uint64_t *d_packed, uint64_t count);
+
+/* ---- E: the curvature loop over the segments of a cloud on several GPUs of one process ---------------------------------
+ * How the reference parallelises it: whole segments are independent units (treee/src/calculations.rs:97-118, one KD-tree
+ * per segment :329), so no data is exchanged at all.  Segments are dealt to the devices by point count (longest first to
+ * the least loaded device; ties: lower segment id, lower list position), each device runs treee_curvature_segments on
+ * its share from its own host thread, results land in curve_out[n] in input order -- bit for bit what one device gives.
+ * devices[n_devices]: HIP device ordinals (an ordinal may repeat: two contexts on one GPU). */
+int32_t treee_curvature_segments_multi(const int32_t *devices, uint32_t n_devices, const float *xyz_aos, const uint32_t *segment,
+                                       uint64_t n, uint32_t n_segments, uint32_t k, float max_dist_sq, float *curve_out);
+int32_t treee_segments_calculate_multi(const int32_t *devices, uint32_t n_devices, const float *xyz_aos, const uint32_t *segment,
+                                       uint64_t n, uint32_t n_segments, float *seg_min_out, float *seg_max_out, float *seg_info_out,
+                                       uint32_t *classification_out, float *expansion_out, float *height_out);
+
 #ifdef __cplusplus
 }
 #endif

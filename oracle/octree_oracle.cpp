@@ -96,11 +96,16 @@ void orc_sort_keys(const uint32_t *keys, uint64_t n, uint32_t *sorted_keys_out, 
 	}
 }
 
-uint64_t orc_octree_build(const uint32_t *keys, uint64_t n, uint32_t leaf_cap, uint32_t lod_cap,
-                          orc_octree_node *nodes_out, uint64_t nodes_cap, uint32_t *leaf_of_sorted,
-                          uint32_t *lod_list, uint64_t lod_cap_total, uint64_t *lod_total_out) {
-	std::vector<orc_octree_node> nodes;
-	if (n > 0) nodes.push_back(orc_octree_node{0, 0, 0, (uint32_t)n, NONE, 0, NONE, NONE});
+// The build from a given front: `roots` are nodes of ONE level whose ranges lie inside keys[0..n) (first relative to keys);
+// everything below them is built breadth first exactly as from the single root.  This is what one rank of a sharded
+// build runs on its owned key range (roots = its nodes of the shard level; include/treee_hip.h "the sharded octree");
+// the whole-cloud build is the same code with the root as the only front node.  Indices in the result are LOCAL (node
+// index = position in nodes_out, roots first; parents of the roots are left as given).
+uint64_t orc_octree_build_from(const uint32_t *keys, uint64_t n, uint32_t leaf_cap, uint32_t lod_cap, const orc_octree_node *roots,
+                               uint64_t n_roots, orc_octree_node *nodes_out, uint64_t nodes_cap, uint32_t *leaf_of_sorted,
+                               uint32_t *lod_list, uint64_t lod_cap_total, uint64_t *lod_total_out) {
+	(void)n;
+	std::vector<orc_octree_node> nodes(roots, roots + n_roots);
 	for (size_t i = 0; i < nodes.size(); ++i) {
 		orc_octree_node nd = nodes[i];
 		if (!(nd.count > leaf_cap && nd.level < DEPTH)) continue;
@@ -141,6 +146,14 @@ uint64_t orc_octree_build(const uint32_t *keys, uint64_t n, uint32_t leaf_cap, u
 	if (nodes_out)
 		for (size_t i = 0; i < nodes.size() && i < nodes_cap; ++i) nodes_out[i] = nodes[i];
 	return nodes.size();
+}
+
+uint64_t orc_octree_build(const uint32_t *keys, uint64_t n, uint32_t leaf_cap, uint32_t lod_cap,
+                          orc_octree_node *nodes_out, uint64_t nodes_cap, uint32_t *leaf_of_sorted,
+                          uint32_t *lod_list, uint64_t lod_cap_total, uint64_t *lod_total_out) {
+	const orc_octree_node root{0, 0, 0, (uint32_t)n, NONE, 0, NONE, NONE};
+	return orc_octree_build_from(keys, n, leaf_cap, lod_cap, &root, n > 0 ? 1 : 0, nodes_out, nodes_cap, leaf_of_sorted, lod_list,
+	                             lod_cap_total, lod_total_out);
 }
 
 } // extern "C"

@@ -92,6 +92,8 @@ def lib():
         L.orc_sort_keys.argtypes = [vp, u64, vp, vp]
         L.orc_octree_build.restype = u64
         L.orc_octree_build.argtypes = [vp, u64, u32, u32, vp, u64, vp, vp, u64, vp]
+        L.orc_octree_build_from.restype = u64
+        L.orc_octree_build_from.argtypes = [vp, u64, u32, u32, vp, u64, vp, u64, vp, vp, u64, vp]
         L.orc_hull_insert_all.restype = u64
         L.orc_hull_insert_all.argtypes = [vp, u64, vp, u64, vp]
         L.orc_size_areas.restype = u64
@@ -308,6 +310,22 @@ def octree_build(sorted_keys, leaf_cap=256, lod_cap=256):
     leaf = np.zeros(n, np.uint32)
     lod = np.zeros(lod_total.value, np.uint32)
     lib().orc_octree_build(_p(sorted_keys), n, leaf_cap, lod_cap, _p(nodes), nn, _p(leaf), _p(lod), len(lod), C.byref(lod_total))
+    return nodes, leaf, lod
+
+
+def octree_build_from(sorted_keys, roots, leaf_cap=256, lod_cap=256):
+    """the build continued from `roots` (NODE_DTYPE, one level, `first` relative to sorted_keys): local node table (roots
+    first), leaf[n] (local node index; positions no root covers keep 0xFFFFFFFF), LOD list (local positions)"""
+    sorted_keys = np.ascontiguousarray(sorted_keys, dtype=np.uint32)
+    roots = np.ascontiguousarray(roots, dtype=NODE_DTYPE)
+    n = len(sorted_keys)
+    lod_total = C.c_uint64(0)
+    nn = lib().orc_octree_build_from(_p(sorted_keys), n, leaf_cap, lod_cap, _p(roots), len(roots), None, 0, None, None, 0, C.byref(lod_total))
+    nodes = np.zeros(nn, NODE_DTYPE)
+    leaf = np.full(n, 0xFFFFFFFF, np.uint32)
+    lod = np.zeros(lod_total.value, np.uint32)
+    lib().orc_octree_build_from(_p(sorted_keys), n, leaf_cap, lod_cap, _p(roots), len(roots), _p(nodes), nn, _p(leaf), _p(lod), len(lod),
+                                C.byref(lod_total))
     return nodes, leaf, lod
 
 

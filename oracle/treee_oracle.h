@@ -159,6 +159,11 @@ uint64_t orc_octree_build(const uint32_t *sorted_keys, uint64_t n, uint32_t leaf
                           uint32_t *leaf_of_sorted, uint32_t *lod_list, uint64_t lod_cap_total,
                           uint64_t *lod_total_out);
 
+/* the same build continued from a given front of nodes of one level (local indices; see octree_oracle.cpp) */
+uint64_t orc_octree_build_from(const uint32_t *sorted_keys, uint64_t n, uint32_t leaf_cap, uint32_t lod_cap,
+                               const orc_octree_node *roots, uint64_t n_roots, orc_octree_node *nodes, uint64_t nodes_cap,
+                               uint32_t *leaf_of_sorted, uint32_t *lod_list, uint64_t lod_cap_total, uint64_t *lod_total_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1276,6 +1276,172 @@ def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path, backend):
     assert int((packed != packed.max()).sum()) > 500
 
 
+# ---- E: the sharded octree (treee_shard_octree_build_dev) ------------------------------------------------------------
+def _assert_assembles_to(T, oracle, pieces, whole, corner, size, leaf_cap, lod_cap):
+    """the pieces of all ranks put together == T.Octree(whole, corner, size): every array, bit for bit"""
+    from treee_amd import octree
+
+    got = octree.assemble(pieces)
+    oc = T.Octree(whole, corner, size, leaf_cap=leaf_cap, lod_cap=lod_cap)
+    for name in ("keys", "perm", "leaf", "lod"):
+        assert np.array_equal(got[name], oc.array(name)), name
+    assert np.array_equal(got["nodes"].view(np.uint32), oc.array("nodes").view(np.uint32))
+    assert np.array_equal(got["sorted_xyz"].view(np.uint32), oc.array("sorted_xyz").view(np.uint32))
+    sk, perm = oracle.sort_keys(oracle.morton_keys(whole, corner, size))  # and the oracle's definition directly
+    nodes, leaf, lod = oracle.octree_build(sk, leaf_cap, lod_cap)
+    assert np.array_equal(got["perm"], perm) and np.array_equal(got["nodes"].view(np.uint32), nodes.view(np.uint32))
+    assert np.array_equal(got["leaf"], leaf) and np.array_equal(got["lod"], lod)
+
+
+@pytest.mark.parametrize("n,top_level,leaf_cap", [(1, 1, 64), (5, 3, 2), (4097, 2, 64), (100_003, 5, 64), (100_003, 0, 256), (300_000, 6, 16)])
+def test_sharded_octree_of_one_rank_is_the_octree(T, oracle, n, top_level, leaf_cap):
+    """world = 1 through the host transport: the replicated top + the rank's forest below the shard level must be the
+    ordinary octree (the split of the build into "top from cell counts" and "levels below from keys" changes nothing)"""
+    import torch
+
+    from treee_amd import distributed as D
+
+    pts = quantised_cloud(n, 900 + n)
+    pts[: n // 3] = pts[: n // 3] * np.float32(0.02) + np.float32(30.0)  # a dense blob: deep cells next to shallow ones
+    comm = D.Comm.host()
+    so = T.ShardedOctree(torch.from_numpy(pts).cuda(), comm, leaf_cap=leaf_cap, lod_cap=32, top_level=top_level)
+    corner, size = cube_of(pts)
+    assert np.array_equal(so.corner, corner) and so.size == size
+    assert so.rank_info.count == n and so.rank_info.first == 0 and so.info.top_level == (top_level or 5)
+    _assert_assembles_to(T, oracle, [so.piece()], pts, corner, size, leaf_cap, 32)
+    with pytest.raises(T.TreeeError):
+        T.KDTree.from_octree(so)  # global indices: no kNN structure over a shard
+    so.close()
+    comm.close()
+
+
+def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import treee_amd as T
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    whole, _ = synth.forest_cloud(400_000, plot=40.0)
+    if layout == "interleaved":
+        pts = whole[rank::world]
+    elif layout == "skewed":
+        cut = [0] + [len(whole) - 700 * (world - 1 - r) for r in range(world)]
+        pts = whole[cut[rank] : cut[rank + 1]]
+    elif layout == "one_empty":
+        pts = whole if rank == 0 else whole[:0]
+    else:
+        pts, _ = synth.forest_cloud(200_000, plot=30.0, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, 30.0))
+    pts = np.ascontiguousarray(pts, np.float32)
+    comm = D.Comm.host()
+    so = T.ShardedOctree(torch.from_numpy(pts).cuda(), comm, leaf_cap=64, lod_cap=32, top_level=top_level)
+    # the frame of the rank's own points, min-reduced through the same communicator (treee_frame_reduce_min_dev)
+    w, h = 160, 90
+    view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 70.0))
+    proj = T.Camera3D(w / h).projection()
+    packed = torch.empty((h, w), dtype=torch.int64, device="cuda")
+    ctx = T.default_context(torch.device("cuda", 0))
+    if len(pts):
+        T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(torch.from_numpy(pts).cuda()), None, len(pts), T.context.ptr(view), T.context.ptr(proj),
+                                             0.3, 0, 0xFFFFFFFF, w, h, T.context.ptr(packed), 0, int(so.rank_info.index_base), None, None))
+    else:
+        packed.fill_((0x3F800000 << 32) | 0xFFFFFFFF)
+    D.frame_reduce_min(packed, comm, ctx)
+    torch.cuda.synchronize()
+    torch.save({"pts": pts, "piece": so.piece(), "corner": so.corner, "size": so.size, "packed": packed.cpu()}, os.path.join(out_dir, f"so{rank}.pt"))
+    so.close()
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,layout,top_level", [(2, "tiles", 0), (2, "interleaved", 4), (3, "skewed", 2), (3, "interleaved", 5), (2, "one_empty", 3)])
+def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_path, world, layout, top_level):
+    """SURVEY 8 E / BASELINE configs[3]: the ranks (sharing this GPU, host transport over gloo) build
+    their pieces of ONE octree -- common cube, Morton-prefix ownership, one all-to-all, replicated top, global numbering --
+    and the pieces are, bit for bit, the octree one GPU builds of the concatenated cloud."""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_sharded_octree_worker, args=(world, port, str(tmp_path), layout, top_level), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"so{r}.pt"), weights_only=False) for r in range(world)]
+    whole = np.concatenate([r["pts"] for r in res])
+    corner, size = cube_of(whole)
+    for r in res:
+        assert np.array_equal(r["corner"], corner) and r["size"] == size
+    _assert_assembles_to(T, oracle, [r["piece"] for r in res], whole, corner, size, 64, 32)
+    counts = [r["piece"]["count"] for r in res]
+    assert sum(counts) == len(whole) and max(counts) - min(counts) <= 0.25 * len(whole) / world
+    # the reduced frame = the frame one GPU draws of the whole cloud
+    w, h = 160, 90
+    view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 70.0))
+    proj = T.Camera3D(w / h).projection()
+    packed = torch.empty((h, w), dtype=torch.int64, device="cuda")
+    ctx = T.default_context(torch.device("cuda", 0))
+    T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(torch.from_numpy(whole).cuda()), None, len(whole), T.context.ptr(view), T.context.ptr(proj),
+                                         0.3, 0, 0xFFFFFFFF, w, h, T.context.ptr(packed), 0, 0, None, None))
+    for r in res:
+        assert torch.equal(r["packed"], packed.cpu())
+
+
+def test_rccl_transport_with_one_rank(T, oracle):
+    """the RCCL transport (librccl opened at run time, ncclCommInitRank, ncclAllGather through the context's stream) with
+    the only communicator a one-GPU box can form: one rank.  The sharded build through it must be the ordinary octree."""
+    import torch
+
+    from treee_amd import distributed as D
+
+    comm = D.Comm.rccl()
+    assert comm.is_rccl and comm.world == 1
+    pts = quantised_cloud(50_000, 31)
+    so = T.ShardedOctree(torch.from_numpy(pts).cuda(), comm, leaf_cap=64, lod_cap=32, top_level=3)
+    corner, size = cube_of(pts)
+    _assert_assembles_to(T, oracle, [so.piece()], pts, corner, size, 64, 32)
+    so.close()
+    comm.close()
+
+
+def test_segments_over_a_device_list(T, oracle):
+    """treee_curvature_segments_multi / treee_segments_calculate_multi: whole segments dealt to the
+    devices of a list, no exchange (calculations.rs:97-118).  A one-GPU box can only list device 0 -- once, and twice (two
+    contexts and two host threads on the same GPU): both must give what the single call gives, bit for bit."""
+    import ctypes as C
+
+    from treee_amd import synth
+
+    pts, seg = synth.forest_cloud(150_000, plot=22.0)
+    seg = seg.astype(np.uint32)
+    nseg = int(seg.max()) + 2  # the last segment is empty
+    whole = T.curvature_segments(pts, seg, nseg)
+    one = T.segments_calculate(pts, seg, nseg)
+    L = T.lib()
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        dv = np.asarray(devices, np.int32)
+        curve = np.full(len(pts), -1.0, np.float32)
+        T._lib.check(L.treee_curvature_segments_multi(T.context.ptr(dv), len(dv), T.context.ptr(pts), T.context.ptr(seg), len(pts), nseg, 31, F32_MAX,
+                                                      T.context.ptr(curve)))
+        assert same_f32(curve, whole), devices
+        mn, mx, info = np.zeros((nseg, 3), np.float32), np.zeros((nseg, 3), np.float32), np.zeros((nseg, 4), np.float32)
+        cls, ex, hg = np.zeros(len(pts), np.uint32), np.zeros(len(pts), np.float32), np.zeros(len(pts), np.float32)
+        T._lib.check(L.treee_segments_calculate_multi(T.context.ptr(dv), len(dv), T.context.ptr(pts), T.context.ptr(seg), len(pts), nseg, T.context.ptr(mn),
+                                                      T.context.ptr(mx), T.context.ptr(info), T.context.ptr(cls), T.context.ptr(ex), T.context.ptr(hg)))
+        for a, b in ((mn, one.min), (mx, one.max), (info, one.info), (ex, one.expansion), (hg, one.height)):
+            assert same_f32(a, b), devices
+        assert np.array_equal(cls, one.classification)
+    bad = np.asarray([7], np.int32)
+    assert L.treee_curvature_segments_multi(T.context.ptr(bad), 1, T.context.ptr(pts), T.context.ptr(seg), len(pts), nseg, 31, F32_MAX, T.context.ptr(curve)) == 1
+
+
 def test_handle_used_from_another_stream_is_ordered(T):
     """Stream contract of include/treee_hip.h ("Streams"): a handle built on one context may be queried through
     another one (another HIP stream) and freed right afterwards; its arrays return to the owner's pool, and the next

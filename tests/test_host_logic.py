@@ -222,3 +222,159 @@ def test_ghost_exchange_world2_gloo(tmp_path):
         p = res[r]["packed"]
         assert p[0, 0] == (0x3F000000 << 32) | 5 and p[1, 1] == (0x3F000000 << 32) | (20_000 + 5)
         assert p[3, 3] == (0x3E000000 << 32) | 0 and p[2, 2] == (0x3F800000 << 32) | 0xFFFFFFFF
+
+
+# ---- the sharded octree on CPU: the protocol of treee_shard_octree_build_dev with the library's
+# own host arithmetic (treee_shard_plan_*: owners, exchange, replicated top, global numbering -- pure host code of the
+# product) and torch.distributed/gloo carrying the data; the device stages (Morton keys, sort, the local build below the
+# shard level) are stood in for by the CPU oracle.  What is checked is what the GPU test checks: the pieces of all ranks
+# assemble into the whole cloud's octree bit for bit.
+def _sharded_octree_cpu_worker(rank, world, port, out_dir, layout, top_level):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from treee_amd import _lib
+    from treee_amd import distributed as D
+    from treee_amd import synth
+    from treee_amd.context import NODE_DTYPE
+
+    leaf_cap, lod_cap, L = 48, 20, top_level
+    whole, _ = synth.forest_cloud(60_000, plot=25.0)
+    if layout == "interleaved":  # every rank holds points from everywhere: almost everything travels
+        pts = whole[rank::world]
+    elif layout == "skewed":  # rank 0 holds nearly all
+        cut = [0] + [len(whole) - 500 * (world - 1 - r) for r in range(world)]
+        pts = whole[cut[rank] : cut[rank + 1]]
+    else:  # x/z tiles: already (almost) the owners' ranges
+        pts, _ = synth.forest_cloud(30_000, plot=20.0, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, 20.0))
+    pts = np.ascontiguousarray(pts, np.float32)
+
+    def gather(a):  # all-gather of equally shaped host arrays -> [world, ...]
+        a = np.ascontiguousarray(a)
+        t = torch.from_numpy(a.view(np.uint8).reshape(-1).copy())  # (gloo moves bytes: it has no unsigned 32-bit type)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return np.stack([p.numpy().view(a.dtype).reshape(a.shape) for p in parts])
+
+    # the common cube: the rule of treee_sort_build over the union (treee_shard_cube_dev)
+    box = gather(np.concatenate([pts.min(0), pts.max(0)]).astype(np.float32))
+    corner = box[:, :3].min(0)
+    size = np.float32((box[:, 3:].max(0) - corner).max())
+    # local sort, points per level-L cell, all-gather, plan
+    keys = O.morton_keys(pts, corner, float(size))
+    skeys, perm = O.sort_keys(keys)
+    cells = np.bincount(skeys >> np.uint32(30 - 3 * L), minlength=8 ** L).astype(np.uint32)
+    plan = D.ShardPlan(gather(cells), L, leaf_cap, lod_cap)
+    me = plan.rank(rank)
+    send_first, send_count, recv_count = plan.exchange(rank)
+    rec = np.zeros((len(pts), 4), np.float32)  # the 16-byte records: (x, y, z, global index)
+    rec[:, :3] = pts[perm]
+    rec[:, 3] = (perm.astype(np.uint32) + np.uint32(me.index_base)).view(np.float32)
+    # the all-to-all (pairwise over gloo)
+    got = []
+    for peer in range(world):
+        out = torch.from_numpy(rec[int(send_first[peer]) : int(send_first[peer] + send_count[peer])].copy())
+        inn = torch.empty((int(recv_count[peer]), 4), dtype=torch.float32)
+        if peer == rank:
+            inn.copy_(out)
+        elif rank < peer:
+            dist.send(out, dst=peer)
+            dist.recv(inn, src=peer)
+        else:
+            dist.recv(inn, src=peer)
+            dist.send(out, dst=peer)
+        got.append(inn.numpy())
+    recv = np.concatenate(got)
+    assert len(recv) == me.count
+    # merge of the received runs = stable sort of their concatenation by key
+    rkeys = O.morton_keys(np.ascontiguousarray(recv[:, :3]), corner, float(size))
+    own_keys, order = O.sort_keys(rkeys)
+    own_rec = recv[order]
+    # the local forest below the rank's nodes of level L, then the global numbering
+    roots = plan.level_nodes(rank)
+    nodes, leaf_local, lod_local = O.octree_build_from(own_keys, roots, leaf_cap, lod_cap)
+    lvl = nodes["level"].astype(np.int64)
+    cnt = np.bincount(lvl, minlength=_lib.SHARD_LEVELS).astype(np.uint32)
+    inner = nodes["first_child"] != 0xFFFFFFFF
+    m = np.minimum(nodes["count"], lod_cap) * inner
+    lodc = np.bincount(lvl, weights=m, minlength=_lib.SHARD_LEVELS).astype(np.uint32)
+    lv = plan.levels(gather(cnt), gather(lodc), rank)
+    lbegin = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int64)
+    own_first = np.array(list(lv.own_node_first), np.int64)
+    gid = (own_first[lvl] + (np.arange(len(nodes)) - lbegin[lvl])).astype(np.uint32)  # local node -> global index
+    g = nodes.copy()
+    g["first"] += np.uint32(me.first)
+    below = lvl > L
+    g["parent"][below] = gid[nodes["parent"][below]]
+    g["first_child"][inner] = gid[nodes["first_child"][inner]]
+    lod_off = np.concatenate([[0], np.cumsum(m)[:-1]]).astype(np.int64)
+    own_lod_first = np.array(list(lv.own_lod_first), np.int64)
+    g["lod_first"][inner] = (own_lod_first[lvl] + (lod_off - lod_off[lbegin[lvl]]))[inner].astype(np.uint32)
+    leaf = np.where(leaf_local != 0xFFFFFFFF, gid[np.minimum(leaf_local, len(nodes) - 1)] if len(nodes) else 0, 0xFFFFFFFF).astype(np.uint32)
+    top = plan.top_nodes()
+    top_lod = np.zeros(plan.info.n_top_lod, np.uint32)
+    for i, nd in enumerate(top):  # the replicated top: LOD samples; a leaf above the shard level covers part of the owned range
+        if nd["first_child"] == 0xFFFFFFFF:
+            a, b = max(int(nd["first"]), int(me.first)), min(int(nd["first"]) + int(nd["count"]), int(me.first + me.count))
+            if a < b:
+                leaf[a - me.first : b - me.first] = i
+        else:
+            mm = min(int(nd["count"]), lod_cap)
+            top_lod[nd["lod_first"] : nd["lod_first"] + mm] = nd["first"] + (np.arange(mm, dtype=np.uint64) * nd["count"]) // mm
+    assert not (leaf == 0xFFFFFFFF).any()
+    piece = {"first": int(me.first), "count": int(me.count), "index_base": int(me.index_base), "top_level": L, "n_total": int(plan.info.n_total),
+             "n_nodes_total": int(lv.n_nodes_total), "n_lod_total": int(lv.n_lod_total),
+             "own_node_first": list(lv.own_node_first), "own_node_count": list(lv.own_node_count),
+             "own_lod_first": list(lv.own_lod_first), "own_lod_count": list(lv.own_lod_count),
+             "keys": own_keys, "perm": own_rec[:, 3].view(np.uint32).copy(), "leaf": leaf, "sorted_xyz": own_rec,
+             "nodes": g.view(NODE_DTYPE), "lod": (lod_local + np.uint32(me.first)).astype(np.uint32), "top_nodes": top, "top_lod": top_lod}
+    torch.save({"pts": pts, "piece": piece, "corner": corner, "size": size, "moved": int(len(pts) - send_count[rank])}, os.path.join(out_dir, f"so{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,layout,top_level", [(2, "tiles", 3), (2, "interleaved", 2), (3, "skewed", 4), (2, "interleaved", 5)])
+def test_sharded_octree_world_gloo_assembles_to_the_whole_octree(tmp_path, world, layout, top_level):
+    """SURVEY 8 E / BASELINE configs[3]: common cube, Morton-range ownership, replicated top, global numbering -- the shards'
+    pieces put together ARE the octree of the whole cloud (keys, permutation, node table, leaf ids, LOD lists), bit for bit"""
+    from oracle import oracle as O
+    from treee_amd import octree
+
+    O.build()
+    mp.spawn(_sharded_octree_cpu_worker, args=(world, _free_port(), str(tmp_path), layout, top_level), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"so{r}.pt"), weights_only=False) for r in range(world)]
+    whole = np.concatenate([r["pts"] for r in res])
+    corner, size = res[0]["corner"], float(res[0]["size"])
+    assert np.array_equal(corner, whole.min(0)) and size == float((whole.max(0) - whole.min(0)).max())
+    got = octree.assemble([r["piece"] for r in res])
+    sk, perm = O.sort_keys(O.morton_keys(whole, corner, size))
+    nodes, leaf, lod = O.octree_build(sk, 48, 20)
+    assert np.array_equal(got["keys"], sk) and np.array_equal(got["perm"], perm)
+    assert np.array_equal(got["sorted_xyz"][:, :3], whole[perm]) and np.array_equal(got["sorted_xyz"][:, 3].view(np.uint32), perm)
+    assert len(got["nodes"]) == len(nodes)
+    for f in nodes.dtype.names:
+        assert np.array_equal(got["nodes"][f], nodes[f]), f
+    assert np.array_equal(got["leaf"], leaf) and np.array_equal(got["lod"], lod)
+    if layout == "interleaved":
+        assert sum(r["moved"] for r in res) > 0.3 * len(whole)
+    counts = [r["piece"]["count"] for r in res]
+    assert max(counts) - min(counts) < 0.2 * len(whole) / world + 8 * len(whole) / 8 ** top_level  # balanced up to a few cells
+
+
+def test_shard_plan_edge_cases():
+    """one cell holding everything (some ranks own nothing), an empty cloud, bad arguments"""
+    from treee_amd import distributed as D
+    from treee_amd._lib import TreeeError
+
+    cc = np.zeros((3, 8), np.uint32)
+    cc[:, 5] = (1000, 10, 0)
+    plan = D.ShardPlan(cc, 1, 64, 16)
+    r = [plan.rank(i) for i in range(3)]
+    assert [x.count for x in r] == [0, 0, 1010] or sorted(x.count for x in r) == [0, 0, 1010]
+    assert sum(x.count for x in r) == plan.info.n_total == 1010 and [x.index_base for x in r] == [0, 1000, 1010]
+    assert plan.info.n_top_nodes == 1 and plan.info.n_level_nodes == 1
+    top = plan.top_nodes()
+    assert top[0]["count"] == 1010 and top[0]["first_child"] == 1 and top[0]["child_mask"] == 1 << 5 and top[0]["lod_first"] == 0
+    empty = D.ShardPlan(np.zeros((2, 64), np.uint32), 2)
+    assert empty.info.n_total == 0 and empty.info.n_top_nodes == 0 and empty.rank(1).count == 0
+    with pytest.raises(TreeeError):
+        D.ShardPlan(np.zeros((2, 1), np.uint32), 0)

@@ -15,7 +15,7 @@ from .calculations import (  # noqa: F401
     map_to_u32_dev,
     segments_calculate,
 )
-from .octree import Octree  # noqa: F401
+from .octree import Octree, ShardedOctree  # noqa: F401
 from .render import (  # noqa: F401
     Camera3D,
     PointCloud,

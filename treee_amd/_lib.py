@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("TREEE_HIP_LIB") or os.path.join(_HERE, "lib", "libtre
 TREEE_OK, TREEE_ERR_INVALID, TREEE_ERR_HIP, TREEE_ERR_EMPTY, TREEE_ERR_UNSUPPORTED, TREEE_ERR_NOMEM = range(6)
 _ERR_NAMES = {1: "INVALID", 2: "HIP", 3: "EMPTY", 4: "UNSUPPORTED", 5: "NOMEM"}
 
-OCT_KEYS, OCT_PERM, OCT_NODES, OCT_LEAF, OCT_LOD, OCT_SORTED_XYZ = range(6)
+OCT_KEYS, OCT_PERM, OCT_NODES, OCT_LEAF, OCT_LOD, OCT_SORTED_XYZ, OCT_TOP_NODES, OCT_TOP_LOD = range(8)
+SHARD_LEVELS = 11
 
 
 class TreeeError(RuntimeError):
@@ -35,6 +36,31 @@ class OctreeInfo(C.Structure):
         ("leaf_cap", C.c_uint32),
         ("lod_cap", C.c_uint32),
     ]
+
+
+class ShardPlanInfo(C.Structure):  # treee_shard_plan_info
+    _fields_ = [("n_total", C.c_uint64), ("world", C.c_uint32), ("top_level", C.c_uint32), ("n_top_nodes", C.c_uint32),
+                ("n_top_lod", C.c_uint32), ("n_level_nodes", C.c_uint32), ("leaf_cap", C.c_uint32), ("lod_cap", C.c_uint32)]
+
+
+class ShardPlanRank(C.Structure):  # treee_shard_plan_rank
+    _fields_ = [("cell_begin", C.c_uint32), ("cell_end", C.c_uint32), ("first", C.c_uint64), ("count", C.c_uint64),
+                ("index_base", C.c_uint64), ("level_node_first", C.c_uint32), ("level_node_count", C.c_uint32)]
+
+
+class ShardLevels(C.Structure):  # treee_shard_levels
+    _fields_ = [("n_nodes_total", C.c_uint64), ("n_lod_total", C.c_uint64)] + [
+        (name, C.c_uint32 * SHARD_LEVELS) for name in ("node_begin", "own_node_first", "own_node_count", "lod_begin", "own_lod_first", "own_lod_count")]
+
+
+_CB_GATHER = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+_CB_ALLTOALL = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64),
+                           C.POINTER(C.c_uint64))
+_CB_REDUCE = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64)
+
+
+class CommHostOps(C.Structure):  # treee_comm_host_ops
+    _fields_ = [("user", C.c_void_p), ("all_gather", _CB_GATHER), ("all_to_all_v", _CB_ALLTOALL), ("all_reduce_min_u64", _CB_REDUCE)]
 
 
 # every symbol include/treee_hip.h declares: name -> (restype, argtypes)
@@ -91,6 +117,27 @@ SYMBOLS = {
     "treee_segments_calculate": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "treee_segments_calculate_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "treee_display_values_dev": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "treee_comm_create_host": (_i32, [C.POINTER(CommHostOps), _i32, _i32, _pp]),
+    "treee_rccl_unique_id": (_i32, [_vp]),
+    "treee_comm_create_rccl": (_i32, [_vp, _i32, _i32, _i32, _pp]),
+    "treee_comm_wrap_rccl": (_i32, [_vp, _i32, _i32, _pp]),
+    "treee_comm_destroy": (_i32, [_vp]),
+    "treee_comm_info": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "treee_shard_plan_create": (_i32, [_vp, _i32, _u32, _u32, _u32, _pp]),
+    "treee_shard_plan_free": (_i32, [_vp]),
+    "treee_shard_plan_info_get": (_i32, [_vp, C.POINTER(ShardPlanInfo)]),
+    "treee_shard_plan_rank_get": (_i32, [_vp, _i32, C.POINTER(ShardPlanRank)]),
+    "treee_shard_plan_top_nodes": (_i32, [_vp, _vp]),
+    "treee_shard_plan_level_nodes": (_i32, [_vp, _i32, _vp]),
+    "treee_shard_plan_exchange": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "treee_shard_plan_levels": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(ShardLevels)]),
+    "treee_shard_cube_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, C.POINTER(_f32)]),
+    "treee_shard_octree_build_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, _f32, _u32, _u32, _u32, _pp]),
+    "treee_shard_octree_info_get": (_i32, [_vp, C.POINTER(ShardPlanInfo), C.POINTER(ShardPlanRank), C.POINTER(ShardLevels)]),
+    "treee_shard_exchange_ghosts_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, _u32, _f32, _u64, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
+    "treee_frame_reduce_min_dev": (_i32, [_vp, _vp, _vp, _u64]),
+    "treee_curvature_segments_multi": (_i32, [_vp, _u32, _vp, _vp, _u64, _u32, _u32, _f32, _vp]),
+    "treee_segments_calculate_multi": (_i32, [_vp, _u32, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -136,6 +136,25 @@ __device__ __forceinline__ uint32_t hilbert_of_morton_lut(uint32_t key, const ui
 	return h;
 }
 
+// Morton key pieces (definition: oracle/octree_oracle.cpp): q = clamp(floor(((p - c) / size) * 1024), 0, 1023), NaN -> 0
+__device__ __forceinline__ uint32_t quant10(float p, float c, float size) {
+	float t = ((p - c) / size) * 1024.0f; // IEEE divide (hipcc default is correctly rounded)
+	if (!(t >= 0.0f)) return 0u;          // negative or NaN
+	if (t >= 1024.0f) return 1023u;
+	return (uint32_t)t;
+}
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {
+	v &= 0x3FFu;
+	v = (v | (v << 16)) & 0x030000FFu;
+	v = (v | (v << 8)) & 0x0300F00Fu;
+	v = (v | (v << 4)) & 0x030C30C3u;
+	v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+__device__ __forceinline__ uint32_t morton30(float x, float y, float z, float cx, float cy, float cz, float size) {
+	return spread3(quant10(x, cx, size)) | (spread3(quant10(y, cy, size)) << 1) | (spread3(quant10(z, cz, size)) << 2);
+}
+
 // inclusive wave scan (64 lanes) of u32
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 	const int lane = lane_id();
@@ -310,6 +329,16 @@ int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_sorted_keys, uint64_
 int32_t cube_fetch_async(treee_ctx *ctx, SortedCloud *sc, float h_cube[4]);
 void cube_commit(SortedCloud *sc, const float h_cube[4]);
 int32_t cube_to_host(treee_ctx *ctx, SortedCloud *sc); // both, with a synchronisation of its own (paths without another one)
+
+// is this octree handle a rank's piece of a sharded octree (octree.hip)?  Its indices are global: no kNN structure over it
+bool octree_is_shard(const treee_octree *o);
+// per-block partial boxes of a cloud: d_partial[grid][6] = (min.xyz, max.xyz) (radix_sort.hip)
+int32_t bbox_partials_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, float **d_partial_out, uint32_t *grid_out);
+
+// treee_knn_build_segments_dev with the cube handed in (knn.hip): one device's share of a cloud's segments keeps the whole
+// cloud's cell keys, hence its tie order
+int32_t knn_build_segments_cube(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_segment, uint64_t n, uint32_t n_segments, const float cube[4],
+                                treee_knn **out);
 
 // default context for the host-pointer API (created lazily, one per process)
 int32_t default_ctx(treee_ctx **out);

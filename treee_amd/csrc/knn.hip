@@ -1474,7 +1474,7 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t, const uint32_t *d_bucket_seg = n
 
 // Sorted by (segment, cell key, original index): a 30-bit sort by the Hilbert index of the Morton cell followed by a stable
 // sort on the segment id.
-int32_t build_segmented(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_seg, uint64_t n, uint32_t nseg, treee_knn *t) {
+int32_t build_segmented(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_seg, uint64_t n, uint32_t nseg, treee_knn *t, const float *cube = nullptr) {
 	if (n >= (1ull << 31) - 64ull * nseg) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per shard", (unsigned long long)n);
 	SortedCloud *sc = t->sc.get();
 	sc->device = ctx->device;
@@ -1482,7 +1482,12 @@ int32_t build_segmented(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_se
 	t->owner = ctx;
 	t->segmented = true;
 	t->n_points = n;
-	TREEE_TRY(bbox_dev(ctx, d_xyz, n, sc->corner, &sc->size));
+	if (cube && cube[3] > 0.0f) { // a cube handed in (the whole cloud's, when this is one device's share of the segments)
+		for (int a = 0; a < 3; ++a) sc->corner[a] = cube[a];
+		sc->size = cube[3];
+	} else {
+		TREEE_TRY(bbox_dev(ctx, d_xyz, n, sc->corner, &sc->size));
+	}
 	const uint64_t nb_max = div_up(n, 64) + nseg; // sum over segments of ceil(count / 64) <= n / 64 + nseg
 	sc->n = nb_max * 64;
 	TREEE_TRY(pool_alloc_t(ctx, sc->n, &sc->d_sorted));
@@ -1572,6 +1577,26 @@ int32_t treee_knn_build_segments_dev(treee_ctx *ctx, const float *d_xyz, const u
 	return TREEE_OK;
 }
 
+} // extern "C"
+namespace treee {
+int32_t knn_build_segments_cube(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_segment, uint64_t n, uint32_t n_segments, const float cube[4],
+                                treee_knn **out) {
+	*out = nullptr;
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	treee_knn *t = new treee_knn;
+	t->device = ctx->device;
+	const int32_t rc = build_segmented(ctx, d_xyz, d_segment, n, n_segments, t, cube);
+	if (rc != TREEE_OK) {
+		treee_knn_free(t);
+		return rc;
+	}
+	*out = t;
+	return TREEE_OK;
+}
+} // namespace treee
+extern "C" {
+
 int32_t treee_curvature_segments(const float *xyz, const uint32_t *segment, uint64_t n, uint32_t n_segments, uint32_t k, float max_dist_sq,
                                  float *curve_out) {
 	if (n == 0) return TREEE_OK;
@@ -1627,6 +1652,7 @@ int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, tree
 
 int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_knn **out) {
 	if (!ctx || !o || !out) return set_err(TREEE_ERR_INVALID, "treee_knn_from_octree_dev: null argument");
+	if (octree_is_shard(o)) return set_err(TREEE_ERR_UNSUPPORTED, "treee_knn_from_octree_dev: a sharded octree's indices are global; build the kNN structure from the rank's own + ghost points");
 	*out = nullptr;
 	std::shared_ptr<SortedCloud> sc = octree_sorted_cloud(o);
 	if (sc->n == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");

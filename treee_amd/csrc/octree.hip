@@ -6,7 +6,9 @@
 // 3 key bits inside its sorted range, found by binary search (8 lanes per parent, one
 // boundary each), so the per-point arrays are touched only by the final leaf-id and LOD
 // kernels (4 B/point written, coalesced).
+#include "comm.h"
 #include "common.h"
+#include "shard_plan.h"
 
 using namespace treee;
 
@@ -20,6 +22,14 @@ struct treee_octree {
 	uint32_t leaf_cap = 256, lod_cap = 256;
 	int device = 0;
 	treee_ctx *owner = nullptr;
+	// a rank's piece of a sharded octree (treee_shard_octree_build_dev): the arrays above hold the owned range and the own
+	// nodes of levels >= top_level with GLOBAL indices; the top of the tree is replicated
+	bool shard = false;
+	treee_shard_plan_info sh_info{};
+	treee_shard_plan_rank sh_rank{};
+	treee_shard_levels sh_levels{};
+	treee_octree_node *d_top_nodes = nullptr;
+	uint32_t *d_top_lod = nullptr;
 };
 // (the octree's own arrays are only ever touched by its owner's stream and by the caller through
 // treee_octree_dev_ptr, whose ordering is the caller's; the shared sorted cloud carries a HandleSync)
@@ -231,10 +241,330 @@ int32_t build_octree_on(treee_ctx *ctx, treee_octree *o) {
 	return TREEE_OK;
 }
 
+
+// ---- the sharded octree (treee_hip.h "the sharded octree") ---------------------------------
+// points of every level-L cell in a rank's locally sorted keys: two binary searches per cell
+__global__ __launch_bounds__(256) void k_cell_counts(const uint32_t *__restrict__ keys, uint32_t n, uint32_t shift, uint32_t ncell,
+                                                      uint32_t *__restrict__ counts) {
+	const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+	if (c >= ncell) return;
+	const uint32_t a = lower_bound_prefix(keys, 0u, n, shift, c);
+	counts[c] = lower_bound_prefix(keys, a, n, shift, c + 1u) - a;
+}
+// local original index -> global index (records' .w and / or a permutation array)
+__global__ __launch_bounds__(256) void k_add_index_base(float4 *__restrict__ rec, uint32_t *__restrict__ perm, uint32_t n, uint32_t base) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	if (rec) rec[i].w = __uint_as_float(__float_as_uint(rec[i].w) + base);
+	if (perm) perm[i] += base;
+}
+__global__ __launch_bounds__(256) void k_keys_from_records(const float4 *__restrict__ rec, uint32_t n, float cx, float cy, float cz, float size,
+                                                            uint32_t *__restrict__ keys) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const float4 p = rec[i];
+	keys[i] = morton30(p.x, p.y, p.z, cx, cy, cz, size);
+}
+// received records (runs of the senders, rank order) -> the owned range in (key, global index) order
+__global__ __launch_bounds__(256) void k_gather_records(const uint32_t *__restrict__ from, const float4 *__restrict__ in, uint32_t n,
+                                                         float4 *__restrict__ out, uint32_t *__restrict__ perm) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const float4 p = in[from[i]];
+	out[i] = p;
+	perm[i] = __float_as_uint(p.w);
+}
+__global__ void k_forest_roots(uint32_t *lvl, uint32_t n_roots) {
+	lvl[0] = 0;
+	lvl[1] = n_roots;
+}
+// own nodes and LOD entries per level: out[l] = nodes, out[LEVELS + l] = LOD entries (level table: pairs (begin, count))
+__global__ void k_level_sums(const uint32_t *__restrict__ lvl, uint32_t first_level, const uint32_t *__restrict__ lcnt,
+                             const uint32_t *__restrict__ loff, uint32_t *__restrict__ out) {
+	const uint32_t l = threadIdx.x;
+	if (l >= TREEE_SHARD_LEVELS) return;
+	uint32_t begin = 0, count = 0;
+	if (l >= first_level) {
+		begin = lvl[2 * l];
+		count = lvl[2 * l + 1];
+	}
+	out[l] = count;
+	out[TREEE_SHARD_LEVELS + l] = count ? loff[begin + count - 1u] + lcnt[begin + count - 1u] - loff[begin] : 0u;
+	out[2 * TREEE_SHARD_LEVELS + l] = begin;
+}
+struct ShardFix {
+	uint32_t L, g0;
+	uint32_t lbegin[TREEE_SHARD_LEVELS];    // first local node of a level
+	uint32_t own_first[TREEE_SHARD_LEVELS]; // its global index
+	uint32_t lod_first[TREEE_SHARD_LEVELS]; // global LOD offset of the rank's first entry of a level
+};
+// local numbering -> global numbering, in place
+__global__ __launch_bounds__(256) void k_shard_fix(treee_octree_node *__restrict__ nodes, uint32_t n_nodes, const uint32_t *__restrict__ loff, ShardFix f) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_nodes) return;
+	treee_octree_node nd = nodes[i];
+	const uint32_t l = nd.level;
+	nd.first += f.g0;
+	if (l > f.L) nd.parent = f.own_first[l - 1u] + (nd.parent - f.lbegin[l - 1u]);
+	if (nd.first_child != NONE32) {
+		nd.first_child = f.own_first[l + 1u] + (nd.first_child - f.lbegin[l + 1u]);
+		nd.lod_first = f.lod_first[l] + (loff[i] - loff[f.lbegin[l]]);
+	}
+	nodes[i] = nd;
+}
+// one wave per own node (global fields already in place): leaves stamp their GLOBAL index over their part of the owned
+// range, inner nodes emit their LOD samples as global sorted positions (stored in local node order)
+__global__ __launch_bounds__(256) void k_shard_finish(const treee_octree_node *__restrict__ nodes, uint32_t n_nodes, uint32_t lod_cap,
+                                                       const uint32_t *__restrict__ loff, ShardFix f, uint32_t *__restrict__ leaf,
+                                                       uint32_t *__restrict__ lod) {
+	const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+	if (i >= n_nodes) return;
+	const int lane = threadIdx.x & 63;
+	const treee_octree_node nd = nodes[i];
+	if (nd.first_child == NONE32) {
+		const uint32_t gid = f.own_first[nd.level] + (i - f.lbegin[nd.level]);
+		for (uint32_t j = lane; j < nd.count; j += 64) leaf[nd.first - f.g0 + j] = gid;
+	} else {
+		const uint32_t m = nd.count < lod_cap ? nd.count : lod_cap;
+		const uint32_t off = loff[i];
+		for (uint32_t j = lane; j < m; j += 64) lod[off + j] = nd.first + (uint32_t)(((uint64_t)j * nd.count) / m);
+	}
+}
+// the replicated top: LOD samples of its inner nodes; a leaf above the shard level stamps the part of the owned range it covers
+__global__ __launch_bounds__(256) void k_top_finish(const treee_octree_node *__restrict__ top, uint32_t n_top, uint32_t lod_cap, uint32_t g0,
+                                                     uint32_t n_own, uint32_t *__restrict__ leaf, uint32_t *__restrict__ top_lod) {
+	const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+	if (i >= n_top) return;
+	const int lane = threadIdx.x & 63;
+	const treee_octree_node nd = top[i];
+	if (nd.first_child == NONE32) {
+		const uint32_t a = nd.first > g0 ? nd.first : g0;
+		const uint64_t e0 = (uint64_t)nd.first + nd.count, e1 = (uint64_t)g0 + n_own;
+		const uint32_t b = (uint32_t)(e0 < e1 ? e0 : e1);
+		for (uint32_t j = a + lane; j < b; j += 64) leaf[j - g0] = i;
+	} else {
+		const uint32_t m = nd.count < lod_cap ? nd.count : lod_cap;
+		for (uint32_t j = lane; j < m; j += 64) top_lod[nd.lod_first + j] = nd.first + (uint32_t)(((uint64_t)j * nd.count) / m);
+	}
+}
+
+int32_t shard_cube(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64_t n, float corner[3], float *size_out) {
+	float mine[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+	if (n) {
+		float *d_partial = nullptr;
+		uint32_t grid = 0;
+		TREEE_TRY(bbox_partials_dev(ctx, d_xyz, n, &d_partial, &grid));
+		std::vector<float> h((size_t)grid * 6);
+		TREEE_HIP(hipMemcpyAsync(h.data(), d_partial, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+		TREEE_HIP(hipStreamSynchronize(ctx->stream));
+		for (uint32_t b = 0; b < grid; ++b)
+			for (int a = 0; a < 3; ++a) {
+				mine[a] = fminf(mine[a], h[b * 6 + a]);
+				mine[3 + a] = fmaxf(mine[3 + a], h[b * 6 + 3 + a]);
+			}
+	}
+	std::vector<float> all((size_t)comm->world * 6);
+	TREEE_TRY(comm->all_gather_host(ctx, mine, all.data(), sizeof(mine)));
+	float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, size = 0.0f;
+	for (int r = 0; r < comm->world; ++r)
+		for (int a = 0; a < 3; ++a) {
+			mn[a] = fminf(mn[a], all[(size_t)r * 6 + a]);
+			mx[a] = fmaxf(mx[a], all[(size_t)r * 6 + 3 + a]);
+		}
+	for (int a = 0; a < 3; ++a) { // the rules of bbox_dev (radix_sort.hip): largest extent; degenerate or non-finite -> 1 / 0
+		const float e = mx[a] - mn[a];
+		if (e > size) size = e;
+		corner[a] = (mn[a] > -INFINITY && mn[a] < INFINITY) ? mn[a] : 0.0f;
+	}
+	if (!(size > 0.0f) || !(size < INFINITY)) size = 1.0f;
+	*size_out = size;
+	return TREEE_OK;
+}
+
+int32_t shard_build(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64_t n, const float *corner_in, float size_in, uint32_t top_level,
+                    treee_octree *o) {
+	hipStream_t st = ctx->stream;
+	const int world = comm->world, rank = comm->rank;
+	const uint32_t L = top_level, ncell = 1u << (3u * L);
+	float corner[3] = {0, 0, 0}, size = size_in;
+	if (corner_in && size_in > 0.0f)
+		for (int a = 0; a < 3; ++a) corner[a] = corner_in[a];
+	else
+		TREEE_TRY(shard_cube(ctx, comm, d_xyz, n, corner, &size));
+	// 1. the rank's input in (key, input order): the ordinary Morton sort with the common cube
+	SortedCloud local;
+	TREEE_TRY(build_sorted_cloud(ctx, d_xyz, n, corner, size, &local));
+	// 2. points per level-L cell, all ranks
+	uint32_t *d_counts = nullptr;
+	TREEE_TRY(ctx->alloc_t(ncell, &d_counts));
+	hipLaunchKernelGGL(k_cell_counts, dim3(div_up(ncell, 256)), dim3(256), 0, st, local.d_keys, (uint32_t)n, 30u - 3u * L, ncell, d_counts);
+	TREEE_LAUNCH_CHECK();
+	std::vector<uint32_t> h_counts(ncell), all_counts((size_t)world * ncell);
+	TREEE_HIP(hipMemcpyAsync(h_counts.data(), d_counts, (size_t)ncell * 4, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipStreamSynchronize(st));
+	TREEE_TRY(comm->all_gather_host(ctx, h_counts.data(), all_counts.data(), (size_t)ncell * 4));
+	// 3. the plan: owners, the top of the tree, what travels
+	treee_shard_plan *plan_raw = nullptr;
+	TREEE_TRY(treee_shard_plan_create(all_counts.data(), world, L, o->leaf_cap, o->lod_cap, &plan_raw));
+	std::unique_ptr<treee_shard_plan> plan(plan_raw);
+	TREEE_TRY(treee_shard_plan_info_get(plan.get(), &o->sh_info));
+	TREEE_TRY(treee_shard_plan_rank_get(plan.get(), rank, &o->sh_rank));
+	const uint64_t n_own = o->sh_rank.count;
+	const uint32_t g0 = (uint32_t)o->sh_rank.first, base = (uint32_t)o->sh_rank.index_base;
+	std::vector<uint64_t> send_first(world), send_count(world), recv_count(world);
+	TREEE_TRY(treee_shard_plan_exchange(plan.get(), rank, send_first.data(), send_count.data(), recv_count.data()));
+	bool anything_moves = false; // (a property of the all-gathered counts: every rank decides alike)
+	for (int s = 0; s < world && !anything_moves; ++s) {
+		const uint32_t *c = all_counts.data() + (size_t)s * ncell;
+		for (uint32_t i = 0; i < ncell && !anything_moves; ++i)
+			anything_moves = c[i] != 0 && !(i >= plan->cell_begin[s] && i < plan->cell_begin[s + 1]);
+	}
+	SortedCloud *sc = o->sc.get();
+	sc->n = n_own;
+	sc->device = ctx->device;
+	sc->owner = ctx;
+	for (int a = 0; a < 3; ++a) sc->corner[a] = corner[a];
+	sc->size = size;
+	sc->crowded = 0;
+	if (!anything_moves) { // the input already is tiled by the owners' key ranges: the local sort is the owned range
+		if (n) hipLaunchKernelGGL(k_add_index_base, dim3(div_up(n, 256)), dim3(256), 0, st, local.d_sorted, local.d_perm, (uint32_t)n, base);
+		TREEE_LAUNCH_CHECK();
+		std::swap(sc->d_keys, local.d_keys);
+		std::swap(sc->d_perm, local.d_perm);
+		std::swap(sc->d_sorted, local.d_sorted);
+	} else {
+		// 4. one all-to-all of 16-byte records (x, y, z, global index); a rank's pieces are contiguous in its sorted order
+		if (n) hipLaunchKernelGGL(k_add_index_base, dim3(div_up(n, 256)), dim3(256), 0, st, local.d_sorted, (uint32_t *)nullptr, (uint32_t)n, base);
+		TREEE_LAUNCH_CHECK();
+		std::vector<uint64_t> s_off(world), s_len(world), r_off(world), r_len(world);
+		uint64_t acc = 0;
+		for (int r = 0; r < world; ++r) {
+			s_off[r] = send_first[r] * 16;
+			s_len[r] = send_count[r] * 16;
+			r_off[r] = acc * 16;
+			r_len[r] = recv_count[r] * 16;
+			acc += recv_count[r];
+		}
+		if (acc != n_own) return set_err(TREEE_ERR_INVALID, "sharded octree: the plan's receive counts (%llu) and owned range (%llu) disagree", (unsigned long long)acc, (unsigned long long)n_own);
+		const size_t cnt = n_own ? n_own : 1;
+		float4 *d_recv = nullptr;
+		uint32_t *d_keys_raw = nullptr, *d_from = nullptr;
+		TREEE_TRY(ctx->alloc_t(cnt, &d_recv));
+		TREEE_TRY(ctx->alloc_t(cnt, &d_keys_raw));
+		TREEE_TRY(ctx->alloc_t(cnt, &d_from));
+		TREEE_TRY(comm->all_to_all_v_dev(ctx, local.d_sorted, s_off.data(), s_len.data(), d_recv, r_off.data(), r_len.data()));
+		// 5. the received runs are sorted by (key, global index) each and arrive in rank order, so one stable sort by key of
+		// their concatenation is the owned range of the whole cloud's order
+		TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_keys));
+		TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_perm));
+		TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_sorted));
+		if (n_own) {
+			hipLaunchKernelGGL(k_keys_from_records, dim3(div_up(n_own, 256)), dim3(256), 0, st, d_recv, (uint32_t)n_own, corner[0], corner[1], corner[2], size, d_keys_raw);
+			TREEE_LAUNCH_CHECK();
+			TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n_own, 30, sc->d_keys, d_from));
+			hipLaunchKernelGGL(k_gather_records, dim3(div_up(n_own, 256)), dim3(256), 0, st, d_from, d_recv, (uint32_t)n_own, sc->d_sorted, sc->d_perm);
+			TREEE_LAUNCH_CHECK();
+		}
+	}
+	// 6. the local forest: the rank's nodes of level L are its roots; everything below them is the ordinary build
+	const uint32_t n_roots = o->sh_rank.level_node_count;
+	const uint64_t per_level = 8ull * (n_own / ((uint64_t)o->leaf_cap + 1ull)) + 8ull;
+	uint32_t lvl_cap[DEPTH + 1] = {};
+	uint64_t nodes_cap = 0, pow8 = 1;
+	for (uint32_t l = 0; l <= DEPTH; ++l) {
+		if (l >= L) {
+			lvl_cap[l] = (uint32_t)(pow8 < per_level ? pow8 : per_level);
+			if (l == L && lvl_cap[l] < n_roots) lvl_cap[l] = n_roots; // (a root's parent may hold most of its points elsewhere)
+			nodes_cap += lvl_cap[l];
+		}
+		pow8 *= 8ull;
+	}
+	TREEE_TRY(pool_alloc_t(ctx, nodes_cap ? nodes_cap : 1, &o->d_nodes));
+	o->nodes_cap = nodes_cap;
+	std::vector<treee_octree_node> roots(n_roots ? n_roots : 1);
+	TREEE_TRY(treee_shard_plan_level_nodes(plan.get(), rank, roots.data()));
+	if (n_roots) TREEE_HIP(hipMemcpyAsync(o->d_nodes, roots.data(), (size_t)n_roots * sizeof(treee_octree_node), hipMemcpyHostToDevice, st));
+	uint32_t *d_lvl = nullptr, *d_total = nullptr;
+	TREEE_TRY(ctx->alloc_t(2 * (DEPTH + 2), &d_lvl));
+	TREEE_TRY(ctx->alloc_t(2, &d_total));
+	hipLaunchKernelGGL(k_forest_roots, dim3(1), dim3(1), 0, st, d_lvl + 2 * L, n_roots);
+	for (uint32_t level = L; level < DEPTH; ++level) {
+		const uint32_t cap = lvl_cap[level];
+		uint32_t *d_cnt = nullptr, *d_off = nullptr, *d_bounds = nullptr;
+		TREEE_TRY(ctx->alloc_t(cap, &d_cnt));
+		TREEE_TRY(ctx->alloc_t(cap, &d_off));
+		TREEE_TRY(ctx->alloc_t((size_t)cap * 8, &d_bounds));
+		const uint32_t grid = div_up((uint64_t)cap * 8, 256);
+		hipLaunchKernelGGL(k_oct_split, dim3(grid), dim3(256), 0, st, sc->d_keys, o->d_nodes, d_lvl + 2 * level, cap, o->leaf_cap, d_cnt, d_bounds);
+		TREEE_LAUNCH_CHECK();
+		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_cnt, d_off, cap, d_total, d_lvl + 2 * level + 1));
+		hipLaunchKernelGGL(k_oct_emit, dim3(grid), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * level, d_off, d_bounds, d_total);
+		TREEE_LAUNCH_CHECK();
+	}
+	uint32_t *d_lcnt = nullptr, *d_loff = nullptr, *d_sums = nullptr;
+	TREEE_TRY(ctx->alloc_t(nodes_cap ? nodes_cap : 1, &d_lcnt));
+	TREEE_TRY(ctx->alloc_t(nodes_cap ? nodes_cap : 1, &d_loff));
+	TREEE_TRY(ctx->alloc_t(3 * TREEE_SHARD_LEVELS, &d_sums));
+	if (nodes_cap) {
+		hipLaunchKernelGGL(k_oct_lod_count, dim3(div_up(nodes_cap, 256)), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * DEPTH, (uint32_t)nodes_cap, o->lod_cap, d_lcnt);
+		TREEE_LAUNCH_CHECK();
+		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_lcnt, d_loff, nodes_cap, d_total));
+	}
+	hipLaunchKernelGGL(k_level_sums, dim3(1), dim3(64), 0, st, d_lvl, L, d_lcnt, d_loff, d_sums);
+	TREEE_LAUNCH_CHECK();
+	uint32_t h_sums[3 * TREEE_SHARD_LEVELS];
+	TREEE_HIP(hipMemcpyAsync(h_sums, d_sums, sizeof(h_sums), hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipStreamSynchronize(st));
+	// 7. every rank's nodes and LOD entries per level -> the global numbering
+	std::vector<uint32_t> all_sums((size_t)world * 2 * TREEE_SHARD_LEVELS), lc((size_t)world * TREEE_SHARD_LEVELS), dc((size_t)world * TREEE_SHARD_LEVELS);
+	TREEE_TRY(comm->all_gather_host(ctx, h_sums, all_sums.data(), 2 * TREEE_SHARD_LEVELS * 4));
+	for (int r = 0; r < world; ++r)
+		for (uint32_t l = 0; l < TREEE_SHARD_LEVELS; ++l) {
+			lc[(size_t)r * TREEE_SHARD_LEVELS + l] = all_sums[(size_t)r * 2 * TREEE_SHARD_LEVELS + l];
+			dc[(size_t)r * TREEE_SHARD_LEVELS + l] = all_sums[(size_t)r * 2 * TREEE_SHARD_LEVELS + TREEE_SHARD_LEVELS + l];
+		}
+	TREEE_TRY(treee_shard_plan_levels(plan.get(), lc.data(), dc.data(), rank, &o->sh_levels));
+	ShardFix fix{};
+	fix.L = L;
+	fix.g0 = g0;
+	uint64_t n_nodes = 0, n_lod = 0;
+	for (uint32_t l = 0; l < TREEE_SHARD_LEVELS; ++l) {
+		fix.lbegin[l] = h_sums[2 * TREEE_SHARD_LEVELS + l];
+		fix.own_first[l] = o->sh_levels.own_node_first[l];
+		fix.lod_first[l] = o->sh_levels.own_lod_first[l];
+		if (l >= L) {
+			n_nodes += h_sums[l];
+			n_lod += h_sums[TREEE_SHARD_LEVELS + l];
+		}
+	}
+	o->n_nodes = n_nodes;
+	o->n_lod = n_lod;
+	// 8. leaf ids, LOD lists, the replicated top
+	const uint32_t n_top = o->sh_info.n_top_nodes, n_top_lod = o->sh_info.n_top_lod;
+	TREEE_TRY(pool_alloc_t(ctx, n_own ? n_own : 1, &o->d_leaf));
+	TREEE_TRY(pool_alloc_t(ctx, n_lod ? n_lod : 1, &o->d_lod));
+	TREEE_TRY(pool_alloc_t(ctx, n_top ? n_top : 1, &o->d_top_nodes));
+	TREEE_TRY(pool_alloc_t(ctx, n_top_lod ? n_top_lod : 1, &o->d_top_lod));
+	if (n_top) TREEE_HIP(hipMemcpyAsync(o->d_top_nodes, plan->top.data(), (size_t)n_top * sizeof(treee_octree_node), hipMemcpyHostToDevice, st));
+	if (n_nodes) {
+		hipLaunchKernelGGL(k_shard_fix, dim3(div_up(n_nodes, 256)), dim3(256), 0, st, o->d_nodes, (uint32_t)n_nodes, d_loff, fix);
+		hipLaunchKernelGGL(k_shard_finish, dim3(div_up(n_nodes, 4)), dim3(256), 0, st, o->d_nodes, (uint32_t)n_nodes, o->lod_cap, d_loff, fix, o->d_leaf, o->d_lod);
+		TREEE_LAUNCH_CHECK();
+	}
+	if (n_top) {
+		hipLaunchKernelGGL(k_top_finish, dim3(div_up(n_top, 4)), dim3(256), 0, st, o->d_top_nodes, n_top, o->lod_cap, g0, (uint32_t)n_own, o->d_leaf, o->d_top_lod);
+		TREEE_LAUNCH_CHECK();
+	}
+	TREEE_HIP(hipStreamSynchronize(st)); // (the uploads above read host vectors that end with this frame)
+	o->shard = true;
+	return TREEE_OK;
+}
+
 } // namespace
 
 namespace treee {
 std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o) { return o->sc; }
+bool octree_is_shard(const treee_octree *o) { return o && o->shard; }
 } // namespace treee
 
 extern "C" {
@@ -339,6 +669,50 @@ int32_t treee_sort_build(const float *xyz, uint64_t n, const float corner[3], fl
 	return TREEE_OK;
 }
 
+int32_t treee_shard_cube_dev(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64_t n, float corner_out[3], float *size_out) {
+	if (!ctx || !comm || !corner_out || !size_out || (n && !d_xyz)) return set_err(TREEE_ERR_INVALID, "treee_shard_cube_dev: null argument");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	return shard_cube(ctx, comm, d_xyz, n, corner_out, size_out);
+}
+
+int32_t treee_shard_octree_build_dev(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64_t n, const float corner[3], float size,
+                                     uint32_t leaf_cap, uint32_t lod_cap, uint32_t top_level, treee_octree **out) {
+	if (!ctx || !comm || !out || (n && !d_xyz)) return set_err(TREEE_ERR_INVALID, "treee_shard_octree_build_dev: null argument");
+	*out = nullptr;
+	if (top_level == 0) top_level = 5;
+	if (top_level > 6) return set_err(TREEE_ERR_INVALID, "treee_shard_octree_build_dev: top_level %u outside [1, 6]", top_level);
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	treee_octree *o = new treee_octree;
+	o->device = ctx->device;
+	o->owner = ctx;
+	o->leaf_cap = leaf_cap ? leaf_cap : 256;
+	o->lod_cap = lod_cap ? lod_cap : 256;
+	int32_t rc;
+	try {
+		rc = shard_build(ctx, comm, d_xyz, n, corner, size, top_level, o);
+	} catch (const std::exception &e) {
+		rc = set_err(TREEE_ERR_NOMEM, "treee_shard_octree_build_dev: %s", e.what());
+	}
+	if (rc != TREEE_OK) {
+		(void)hipStreamSynchronize(ctx->stream); // nothing in flight may still read this frame's host buffers
+		treee_octree_free(o);
+		return rc;
+	}
+	*out = o;
+	return TREEE_OK;
+}
+
+int32_t treee_shard_octree_info_get(const treee_octree *o, treee_shard_plan_info *info, treee_shard_plan_rank *rank, treee_shard_levels *levels) {
+	if (!o) return set_err(TREEE_ERR_INVALID, "treee_shard_octree_info_get: null argument");
+	if (!o->shard) return set_err(TREEE_ERR_INVALID, "treee_shard_octree_info_get: not a sharded octree");
+	if (info) *info = o->sh_info;
+	if (rank) *rank = o->sh_rank;
+	if (levels) *levels = o->sh_levels;
+	return TREEE_OK;
+}
+
 int32_t treee_octree_free(treee_octree *o) {
 	if (!o) return TREEE_OK;
 	(void)hipSetDevice(o->device);
@@ -346,6 +720,8 @@ int32_t treee_octree_free(treee_octree *o) {
 	pool_release(o->owner, o->d_nodes);
 	pool_release(o->owner, o->d_leaf);
 	pool_release(o->owner, o->d_lod);
+	pool_release(o->owner, o->d_top_nodes);
+	pool_release(o->owner, o->d_top_lod);
 	delete o;
 	return TREEE_OK;
 }
@@ -370,6 +746,8 @@ static int32_t oct_array(const treee_octree *o, int32_t what, const void **p, ui
 	case TREEE_OCT_LEAF: *p = o->d_leaf; *bytes = o->sc->n * 4; break;
 	case TREEE_OCT_LOD: *p = o->d_lod; *bytes = o->n_lod * 4; break;
 	case TREEE_OCT_SORTED_XYZ: *p = o->sc->d_sorted; *bytes = o->sc->n * 16; break;
+	case TREEE_OCT_TOP_NODES: *p = o->d_top_nodes; *bytes = o->shard ? o->sh_info.n_top_nodes * sizeof(treee_octree_node) : 0; break;
+	case TREEE_OCT_TOP_LOD: *p = o->d_top_lod; *bytes = o->shard ? (uint64_t)o->sh_info.n_top_lod * 4 : 0; break;
 	default: return set_err(TREEE_ERR_INVALID, "unknown octree array id %d", what);
 	}
 	return TREEE_OK;

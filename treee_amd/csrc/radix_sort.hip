@@ -24,23 +24,7 @@ constexpr int RS_BLOCK = 256;
 constexpr int RS_ITEMS = TREEE_RS_ITEMS;
 constexpr int RS_TILE = RS_BLOCK * RS_ITEMS; // 4096 keys per workgroup
 
-// ---- Morton keys -------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t quant10(float p, float c, float size) {
-	float t = ((p - c) / size) * 1024.0f; // IEEE divide (hipcc default is correctly rounded)
-	if (!(t >= 0.0f)) return 0u;          // negative or NaN
-	if (t >= 1024.0f) return 1023u;
-	return (uint32_t)t;
-}
-
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {
-	v &= 0x3FFu;
-	v = (v | (v << 16)) & 0x030000FFu;
-	v = (v | (v << 8)) & 0x0300F00Fu;
-	v = (v | (v << 4)) & 0x030C30C3u;
-	v = (v | (v << 2)) & 0x09249249u;
-	return v;
-}
-
+// ---- Morton keys (quant10 / spread3: common.h) ----------------------------------------------
 __global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ xyz, uint32_t n,
                                                       float cx, float cy, float cz, float size,
                                                       uint32_t *__restrict__ keys) {
@@ -150,6 +134,17 @@ __global__ __launch_bounds__(256) void k_bbox_final(const float *__restrict__ pa
 		for (int a = 0; a < 3; ++a) cube[a] = (mn[a] > -INFINITY && mn[a] < INFINITY) ? mn[a] : 0.0f;
 		cube[3] = size;
 	}
+}
+
+int32_t bbox_partials_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, float **d_partial_out, uint32_t *grid_out) {
+	const uint32_t grid = n < 256 * 1024 ? div_up(n ? n : 1, 256) : 1024;
+	float *d_partial = nullptr;
+	TREEE_TRY(ctx->alloc_t(grid * 6, &d_partial));
+	hipLaunchKernelGGL(k_bbox_partial, dim3(grid), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, d_partial);
+	TREEE_LAUNCH_CHECK();
+	*d_partial_out = d_partial;
+	*grid_out = grid;
+	return TREEE_OK;
 }
 
 static int32_t bbox_to_device(treee_ctx *ctx, const float *d_xyz, uint64_t n, float *d_cube) {

@@ -23,6 +23,264 @@ import torch
 import torch.distributed as dist
 
 
+class Comm:
+    """treee_comm of the C ABI (include/treee_hip.h, "many GPUs -- communicator"): what the library's sharded entry points
+    talk to the other ranks through.
+
+    * `Comm.rccl(group)`  -- the library's own RCCL communicator (ncclCommInitRank inside libtreee_hip.so; payloads stay in
+      HBM, collectives run on the context's stream).  torch.distributed only carries the 128-byte unique id to the ranks.
+    * `Comm.host(group)`  -- host callbacks over any torch.distributed group (gloo in the tests and rehearsals): the
+      library stages device data through host memory and calls back here for the transport.
+    """
+
+    def __init__(self, handle, rank, world, keep=None):
+        self._h, self.rank, self.world, self._keep = handle, rank, world, keep
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def is_rccl(self):
+        import ctypes as C
+
+        from . import _lib
+
+        flag = C.c_int32()
+        _lib.check(_lib.lib().treee_comm_info(self._h, None, None, C.byref(flag)))
+        return bool(flag.value)
+
+    @classmethod
+    def rccl(cls, group=None, device=None):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            _lib.check(_lib.lib().treee_rccl_unique_id(uid.ctypes.data_as(C.c_void_p)))
+        if world > 1:
+            t = torch.from_numpy(uid)
+            if dist.get_backend(group) != "gloo":
+                t = t.cuda()
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = t.cpu().numpy()
+        dev = torch.cuda.current_device() if device is None else torch.device(device).index
+        h = C.c_void_p()
+        _lib.check(_lib.lib().treee_comm_create_rccl(uid.ctypes.data_as(C.c_void_p), rank, world, dev, C.byref(h)))
+        return cls(h, rank, world)
+
+    @classmethod
+    def host(cls, group=None):
+        """host-staged transport over `group` (any backend that moves CPU tensors; a world of one needs no group)"""
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        live = dist.is_initialized()
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if live else (0, 1)
+
+        def view(p, nbytes):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 1),))[: int(nbytes)]
+
+        def all_gather(_user, send, recv, nbytes):
+            try:
+                src, dst = view(send, nbytes), view(recv, nbytes * world)
+                if world == 1:
+                    dst[:] = src
+                    return 0
+                parts = [torch.empty(int(nbytes), dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, torch.from_numpy(src.copy()), group=group)
+                for r, part in enumerate(parts):
+                    dst[r * nbytes : (r + 1) * nbytes] = part.numpy()
+                return 0
+            except Exception:  # never unwind into C
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def all_to_all_v(_user, send, s_off, s_len, recv, r_off, r_len):
+            try:
+                so, sl, ro, rl = ([int(a[r]) for r in range(world)] for a in (s_off, s_len, r_off, r_len))
+                src = view(send, max(o + n for o, n in zip(so, sl)))
+                dst = view(recv, max(o + n for o, n in zip(ro, rl)))
+                if world == 1:
+                    dst[ro[0] : ro[0] + rl[0]] = src[so[0] : so[0] + sl[0]]
+                    return 0
+                outs = [torch.from_numpy(src[so[r] : so[r] + sl[r]].copy()) for r in range(world)]
+                ins = [torch.empty(rl[r], dtype=torch.uint8) for r in range(world)]
+                # gloo has no all_to_all: pairwise exchange, lower rank sends first (every pair is ordered the same way)
+                for peer in range(world):
+                    if peer == rank:
+                        ins[peer].copy_(outs[peer])
+                    elif rank < peer:
+                        dist.send(outs[peer], dst=_global(group, peer), group=group)
+                        dist.recv(ins[peer], src=_global(group, peer), group=group)
+                    else:
+                        dist.recv(ins[peer], src=_global(group, peer), group=group)
+                        dist.send(outs[peer], dst=_global(group, peer), group=group)
+                for r in range(world):
+                    dst[ro[r] : ro[r] + rl[r]] = ins[r].numpy()
+                return 0
+            except Exception:
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def all_reduce_min_u64(_user, buf, count):
+            try:
+                if world == 1:
+                    return 0
+                a = np.ctypeslib.as_array(buf, shape=(int(count),))
+                t = torch.from_numpy(a.view(np.int64))  # values < 2^63 (depth < 1.0): the signed order is the unsigned one
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                return 0
+            except Exception:
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        ops = _lib.CommHostOps(None, _lib._CB_GATHER(all_gather), _lib._CB_ALLTOALL(all_to_all_v), _lib._CB_REDUCE(all_reduce_min_u64))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().treee_comm_create_host(C.byref(ops), rank, world, C.byref(h)))
+        return cls(h, rank, world, keep=ops)  # (the callbacks must outlive the handle)
+
+    @classmethod
+    def for_group(cls, group=None):
+        """RCCL when the group runs on it, host callbacks otherwise (gloo)."""
+        if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            return cls.rccl(group)
+        return cls.host(group)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            from . import _lib
+
+            _lib.lib().treee_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardPlan:
+    """treee_shard_plan of the C ABI: the host arithmetic of the sharded octree (owners of the Morton cells, what travels
+    where, the replicated top, the global numbering).  Pure host code -- usable without a GPU."""
+
+    def __init__(self, cell_counts, top_level, leaf_cap=256, lod_cap=256):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        cc = np.ascontiguousarray(cell_counts, dtype=np.uint32)
+        assert cc.ndim == 2 and cc.shape[1] == 8 ** top_level
+        self.world = cc.shape[0]
+        h = C.c_void_p()
+        _lib.check(_lib.lib().treee_shard_plan_create(cc.ctypes.data_as(C.c_void_p), self.world, top_level, leaf_cap, lod_cap, C.byref(h)))
+        self._h = h
+        self.info = _lib.ShardPlanInfo()
+        _lib.check(_lib.lib().treee_shard_plan_info_get(h, C.byref(self.info)))
+
+    def rank(self, r):
+        import ctypes as C
+
+        from . import _lib
+
+        out = _lib.ShardPlanRank()
+        _lib.check(_lib.lib().treee_shard_plan_rank_get(self._h, r, C.byref(out)))
+        return out
+
+    def top_nodes(self):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+        from .context import NODE_DTYPE
+
+        out = np.zeros(self.info.n_top_nodes, NODE_DTYPE)
+        _lib.check(_lib.lib().treee_shard_plan_top_nodes(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def level_nodes(self, r):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+        from .context import NODE_DTYPE
+
+        out = np.zeros(self.rank(r).level_node_count, NODE_DTYPE)
+        _lib.check(_lib.lib().treee_shard_plan_level_nodes(self._h, r, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def exchange(self, r):
+        """(send_first, send_count, recv_count), each [world]"""
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        a, b, c = (np.zeros(self.world, np.uint64) for _ in range(3))
+        _lib.check(_lib.lib().treee_shard_plan_exchange(self._h, r, *(x.ctypes.data_as(C.c_void_p) for x in (a, b, c))))
+        return a, b, c
+
+    def levels(self, level_counts, lod_counts, r):
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _lib
+
+        lc = np.ascontiguousarray(level_counts, dtype=np.uint32)
+        dc = np.ascontiguousarray(lod_counts, dtype=np.uint32)
+        assert lc.shape == dc.shape == (self.world, _lib.SHARD_LEVELS)
+        out = _lib.ShardLevels()
+        _lib.check(_lib.lib().treee_shard_plan_levels(self._h, lc.ctypes.data_as(C.c_void_p), dc.ctypes.data_as(C.c_void_p), r, C.byref(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            from . import _lib
+
+            _lib.lib().treee_shard_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def frame_reduce_min(packed, comm, ctx=None):
+    """treee_frame_reduce_min_dev: element-wise MIN of the packed frames of all ranks, in place"""
+    from . import _lib
+    from .context import default_context, ptr
+
+    c = ctx or default_context(packed.device)
+    _lib.check(_lib.lib().treee_frame_reduce_min_dev(c.handle, comm.handle, ptr(packed), packed.numel()))
+    return packed
+
+
+def _global(group, r):
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
 def _host_staged(group=None):
     """gloo cannot move CUDA tensors: rehearsal runs (several ranks sharing one GPU) stage the
     collectives through host memory.  With nccl (= RCCL over xGMI) tensors stay in HBM."""
@@ -153,86 +411,60 @@ def exchange_ghosts(points, bounds, halo, rank, world_size, group=None, ctx=None
 
 
 class GhostExchanger:
-    """The per-step form of `exchange_ghosts` for clouds resident in HBM: ONE collective and ONE host round trip
-    per step instead of two and four.
+    """The per-step ghost exchange for clouds resident in HBM: `treee_shard_exchange_ghosts_dev` behind a buffer policy.
 
     * the cloud lives in a buffer with room for the ghosts behind the own points (`cloud[:n]` = own points,
       `cloud[n:n+g]` = ghosts), so nothing is concatenated;
-    * the send block has a fixed capacity sized by one counted exchange at construction (times `margin`); its
-      row 0 is a header (x = the sender's count as int32 bits, y = z = NaN: never inside a box), unused rows are
-      NaN;
-    * receivers blank their own block and run ONE fused selection over all blocks straight into the ghost region;
-    * the host reads (ghost count, every sender's count) in one copy; a sender that outgrew the capacity is seen
-      by all ranks in the same data, so all of them grow the buffers together and repeat.
+    * ONE collective per step (an all-gather of fixed-capacity blocks whose header row carries the sender's count) and
+      ONE host round trip (the ghost count the sort needs and every sender's count);
+    * a sender that outgrew the capacity is seen by all ranks in the same data, so all of them grow the buffers together
+      and repeat.
     """
 
-    def __init__(self, points, bounds, halo, rank, world_size, ctx=None, group=None, margin=1.5):
+    def __init__(self, points, bounds, halo, rank, world_size, ctx=None, group=None, margin=1.5, comm=None):
         from .context import default_context
 
         assert points.is_cuda and world_size > 1
         self.rank, self.world, self.group, self.bounds = rank, world_size, group, bounds
         self.ctx = ctx or default_context(points.device)
+        self.comm = comm or Comm.for_group(group)
         self.n = points.shape[0]
         self.dev = points.device
         self.margin = margin
-        self.cnt = torch.zeros((2,), dtype=torch.int32, device=self.dev)
-        mine = self._select_boundary(points.contiguous(), halo, None, 0)  # counted once (synchronises)
-        count = torch.tensor([mine], dtype=torch.int64, device=self.dev)
-        most = int(_all_gather_equal(count, world_size, group).max().item())
+        f = _interior_faces(rank, world_size)
+        self.faces = (1 if f[0] else 0) | (2 if f[1] else 0) | (4 if f[2] else 0) | (8 if f[3] else 0)
+        self.cap = 0
+        self.cloud = points.contiguous()
+        ghosts, most = self._call(halo, 0, 0)  # counted once: nothing is written with zero capacities
         self._allocate(points, int(most * margin) + 64)
 
     def _allocate(self, points, cap):
         self.cap = cap
         self.ghost_cap = (self.world - 1) * cap
-        self.send = torch.empty((cap + 1, 3), dtype=torch.float32, device=self.dev)
-        self.recv = torch.empty((self.world, cap + 1, 3), dtype=torch.float32, device=self.dev)
         self.cloud = torch.empty((self.n + self.ghost_cap, 3), dtype=torch.float32, device=self.dev)
         self.cloud[: self.n] = points
 
-    def _select_boundary(self, points, halo, out, cap):
-        """own points within `halo` of a shared face -> out (or just counted when out is None)."""
+    def _call(self, halo, send_cap, ghost_cap):
+        import ctypes as C
+
         import numpy as np
 
         from . import _lib
         from .context import ptr
 
-        faces = _interior_faces(self.rank, self.world)
-        x0, x1, z0, z1 = self.bounds
-        keep = np.asarray((-_INF, _INF, -_INF, _INF), dtype=np.float32)
-        drop = np.asarray((x0 + halo if faces[0] else -_INF, x1 - halo if faces[1] else _INF, z0 + halo if faces[2] else -_INF,
-                           z1 - halo if faces[3] else _INF), dtype=np.float32)
-        _lib.check(_lib.lib().treee_select_xz_dev(self.ctx.handle, ptr(points), points.shape[0], ptr(keep), ptr(drop), ptr(out), cap, ptr(self.cnt)))
-        return int(self.cnt[0].item()) if out is None else None
+        box = np.asarray(self.bounds, dtype=np.float32)
+        g, most = C.c_uint64(), C.c_uint64()
+        _lib.check(_lib.lib().treee_shard_exchange_ghosts_dev(self.ctx.handle, self.comm.handle, ptr(self.cloud), self.n, ptr(box), self.faces, float(halo),
+                                                              send_cap, ghost_cap, C.byref(g), C.byref(most)))
+        return int(g.value), int(most.value)
 
     def exchange(self, halo):
         """refreshes the ghosts behind the own points; returns cloud[: n + ghosts]."""
-        import numpy as np
-
-        from . import _lib
-        from .context import ptr
-
-        x0, x1, z0, z1 = self.bounds
         while True:
-            cap = self.cap
-            self.send.fill_(float("nan"))
-            self._select_boundary(self.cloud[: self.n], halo, self.send[1:], cap)
-            self.send.view(torch.int32)[0, 0:1].copy_(self.cnt[0:1])
-            if _host_staged(self.group):
-                self.recv.copy_(_all_gather_equal(self.send, self.world, self.group))
-            else:
-                dist.all_gather_into_tensor(self.recv.view(-1, 3), self.send, group=self.group)
-            heads = self.recv.view(torch.int32)[:, 0, 0].clone()
-            self.recv[self.rank].fill_(float("nan"))
-            keep = np.asarray((x0 - halo, x1 + halo, z0 - halo, z1 + halo), dtype=np.float32)
-            drop = np.zeros(4, np.float32)
-            flat = self.recv.view(-1, 3)
-            _lib.check(_lib.lib().treee_select_xz_dev(self.ctx.handle, ptr(flat), flat.shape[0], ptr(keep), ptr(drop), ptr(self.cloud[self.n :]),
-                                                      self.ghost_cap, ptr(self.cnt[1:])))
-            info = torch.cat([self.cnt[1:2], heads]).tolist()  # the step's one host round trip
-            ghosts, most = info[0], max(info[1:])
-            if most <= cap and ghosts <= self.ghost_cap:
+            ghosts, most = self._call(halo, self.cap, self.ghost_cap)
+            if most <= self.cap and ghosts <= self.ghost_cap:
                 return self.cloud[: self.n + ghosts]
-            self._allocate(self.cloud[: self.n].clone(), int(max(most, cap) * self.margin) + 64)  # same decision on every rank
+            self._allocate(self.cloud[: self.n].clone(), int(max(most, self.cap) * self.margin) + 64)  # same decision on every rank
 
 
 def halo_is_sufficient(points, kth_dist_sq, bounds, halo, rank, world_size, group=None):

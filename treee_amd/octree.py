@@ -14,6 +14,8 @@ _ARR = {
     "leaf": (_lib.OCT_LEAF, np.uint32, 1),
     "lod": (_lib.OCT_LOD, np.uint32, 1),
     "sorted_xyz": (_lib.OCT_SORTED_XYZ, np.float32, 4),
+    "top_nodes": (_lib.OCT_TOP_NODES, NODE_DTYPE, 1),
+    "top_lod": (_lib.OCT_TOP_LOD, np.uint32, 1),
 }
 
 
@@ -61,7 +63,8 @@ class Octree:
     def array(self, name):
         """copy one of keys / perm / nodes / leaf / lod / sorted_xyz to the host."""
         what, dt, cols = _ARR[name]
-        count = {"nodes": self.n_nodes, "lod": self.n_lod}.get(name, self.n_points)
+        count = {"nodes": self.n_nodes, "lod": self.n_lod, "top_nodes": getattr(self, "n_top_nodes", 0),
+                 "top_lod": getattr(self, "n_top_lod", 0)}.get(name, self.n_points)
         out = np.zeros((count, cols) if cols > 1 else (count,), dt)
         if count:
             _lib.check(_lib.lib().treee_octree_copy(self._h, what, ptr(out), out.nbytes))
@@ -82,3 +85,67 @@ class Octree:
             self.close()
         except Exception:
             pass
+
+
+class ShardedOctree(Octree):
+    """One rank's piece of the octree of a cloud that is spread over the ranks of `comm` (treee_shard_octree_build_dev;
+    SURVEY.md section 8 row E).  Collective: every rank constructs it with its own points.  `assemble` puts the pieces
+    of all ranks together into the single-GPU tables (tests, exports)."""
+
+    def __init__(self, points, comm, corner=None, size=0.0, leaf_cap=256, lod_cap=256, top_level=0, ctx=None):
+        h = C.c_void_p()
+        c = None if corner is None else host_f32(corner).reshape(3)
+        self._deferred = None
+        self.ctx = ctx or default_context(points.device)
+        self.comm = comm
+        p = dev_f32(points, 3)
+        _lib.check(_lib.lib().treee_shard_octree_build_dev(self.ctx.handle, comm.handle, ptr(p), p.shape[0], ptr(c), size, leaf_cap, lod_cap, top_level, C.byref(h)))
+        self._h = h
+        self._refresh()
+        self.info, self.rank_info, self.levels = _lib.ShardPlanInfo(), _lib.ShardPlanRank(), _lib.ShardLevels()
+        _lib.check(_lib.lib().treee_shard_octree_info_get(self._h, C.byref(self.info), C.byref(self.rank_info), C.byref(self.levels)))
+        self.n_top_nodes, self.n_top_lod = self.info.n_top_nodes, self.info.n_top_lod
+
+    def piece(self):
+        """this rank's arrays and numbering as plain host data (what `assemble` consumes)"""
+        lv = self.levels
+        return {
+            "first": int(self.rank_info.first), "count": int(self.rank_info.count), "index_base": int(self.rank_info.index_base),
+            "top_level": int(self.info.top_level), "n_total": int(self.info.n_total),
+            "n_nodes_total": int(lv.n_nodes_total), "n_lod_total": int(lv.n_lod_total),
+            "own_node_first": list(lv.own_node_first), "own_node_count": list(lv.own_node_count),
+            "own_lod_first": list(lv.own_lod_first), "own_lod_count": list(lv.own_lod_count),
+            "keys": self.array("keys"), "perm": self.array("perm"), "leaf": self.array("leaf"), "sorted_xyz": self.array("sorted_xyz"),
+            "nodes": self.array("nodes"), "lod": self.array("lod"), "top_nodes": self.array("top_nodes"), "top_lod": self.array("top_lod"),
+        }
+
+
+def assemble(pieces):
+    """pieces (ShardedOctree.piece() of every rank, rank order) -> dict(keys, perm, sorted_xyz, leaf, nodes, lod) of the
+    whole cloud's octree: the top from any rank (they must agree), every level below it rank after rank."""
+    p0 = pieces[0]
+    for p in pieces[1:]:
+        assert np.array_equal(p["top_nodes"].view(np.uint32), p0["top_nodes"].view(np.uint32)) and np.array_equal(p["top_lod"], p0["top_lod"])
+    n, nn, nl, L = p0["n_total"], p0["n_nodes_total"], p0["n_lod_total"], p0["top_level"]
+    out = {"keys": np.zeros(n, np.uint32), "perm": np.zeros(n, np.uint32), "leaf": np.zeros(n, np.uint32), "sorted_xyz": np.zeros((n, 4), np.float32),
+           "nodes": np.zeros(nn, NODE_DTYPE), "lod": np.zeros(nl, np.uint32)}
+    filled_nodes, filled_lod = np.zeros(nn, bool), np.zeros(nl, bool)
+    nt, ntl = len(p0["top_nodes"]), len(p0["top_lod"])
+    out["nodes"][:nt], out["lod"][:ntl] = p0["top_nodes"], p0["top_lod"]
+    filled_nodes[:nt], filled_lod[:ntl] = True, True
+    for p in pieces:
+        a, c = p["first"], p["count"]
+        for k in ("keys", "perm", "leaf", "sorted_xyz"):
+            out[k][a : a + c] = p[k]
+        no = lo = 0
+        for lvl in range(L, _lib.SHARD_LEVELS):
+            cn, cl = p["own_node_count"][lvl], p["own_lod_count"][lvl]
+            g, gl = p["own_node_first"][lvl], p["own_lod_first"][lvl]
+            assert not filled_nodes[g : g + cn].any() and not filled_lod[gl : gl + cl].any(), "two ranks claim the same node or LOD slots"
+            out["nodes"][g : g + cn] = p["nodes"][no : no + cn]
+            out["lod"][gl : gl + cl] = p["lod"][lo : lo + cl]
+            filled_nodes[g : g + cn], filled_lod[gl : gl + cl] = True, True
+            no, lo = no + cn, lo + cl
+        assert no == len(p["nodes"]) and lo == len(p["lod"])
+    assert filled_nodes.all() and filled_lod.all(), "node or LOD slots nobody owns"
+    return out
