@@ -2,10 +2,16 @@
 """bench.py -- the hot path of BASELINE.json on N GPUs of one node.
 
 A "step" is one pass of the whole path over one synthetic forest cloud that is already
-resident in HBM: [N>1: ghost-point all-gather] -> Morton keys + radix sort + octree/LOD ->
-kNN structure + k=31 neighbours + curvature (treee/src/calculations.rs:328-373) ->
-map_to_u32 -> splat into a 1920x1080 depth+id buffer [N>1: MIN all-reduce of the packed
-frame].  Weak scaling: every rank owns one 15 M-point 200 m x 200 m tile.
+resident in HBM: Morton keys + radix sort + octree/LOD -> kNN structure + k=31 neighbours +
+curvature (treee/src/calculations.rs:328-373) -> map_to_u32 -> splat into a 1920x1080
+depth+id buffer.  At N > 1 every rank owns one x/z tile and the step is the sharded path
+(SURVEY.md section 8 row E): ghost-point all-gather -> the rank's piece of the ONE octree of
+the whole cloud (common cube, Morton-cell ownership, one all-to-all, replicated top:
+treee_shard_octree_build_dev) -> kNN structure over own + ghost points, curvature of the
+own points -> splat of the own points, MIN all-reduce of the packed frame, resolve.
+Default: weak scaling, every rank owns one 15 M-point 200 m x 200 m tile.
+--total-points T: strong scaling, T / N points per rank at the same density
+(BASELINE.json configs[3]: --total-points 150000000).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline      for the dominant kernel (the kNN/curvature kernel), measured live with HIP
@@ -43,6 +49,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=15_000_000, help="points per GPU")
+    ap.add_argument("--total-points", type=int, default=0, help="strong scaling: points of the WHOLE cloud, cut into --gpus tiles of the same density "
+                    "(configs[3]: 150000000); overrides --points / --plot")
+    ap.add_argument("--transport", choices=["auto", "rccl", "host"], default="auto", help="N > 1: the library's RCCL communicator (default under nccl) or "
+                    "host callbacks over the torch group")
     ap.add_argument("--plot", type=float, default=PLOT, help="edge of the square tile in metres (632 with --points 150000000 keeps the density)")
     ap.add_argument("--halo", type=float, default=2.0)
     ap.add_argument("--no-overlap", action="store_true", help="build the octree's node table and the kNN structure one after the other on one stream")
@@ -99,6 +109,9 @@ def main():
     ctx = T.default_context(dev)
     n = args.points
     plot = args.plot
+    if args.total_points:
+        n = args.total_points // world
+        plot = (n / (15_000_000 / PLOT ** 2)) ** 0.5  # the 15 M configuration's 375 points / m^2
     origin = D.tile_origin(rank, world, plot)
     bounds = D.tile_bounds(rank, world, plot)
     pts, seg = synth.forest_cloud_torch(n, dev, plot=plot, seed=synth.SEED_FOREST + rank, origin=origin)
@@ -113,54 +126,55 @@ def main():
     curve = torch.empty((n + n // 8,), dtype=torch.float32, device=dev)
     ctx.reserve(int(n * 1.15) * 48 + (64 << 20))
     overlap = not args.no_overlap
-    side = torch.cuda.Stream(dev) if overlap else None
-    ctx2 = T.Context(dev, side) if overlap else None
-    if overlap:
+    side = torch.cuda.Stream(dev) if (overlap or world > 1) else None
+    ctx2 = T.Context(dev, side) if side is not None else None
+    if side is not None:
         ctx2.reserve(int(n * 1.15) * 24 + (32 << 20))  # node table, leaf ids, LOD lists and the scans' scratch of the side stream
     stages = Stage()
     halo = args.halo
     state = {}
+    comm = None
+    if world > 1:
+        # the library's own communicator: RCCL over xGMI under the nccl backend (torch only carries the unique id), host
+        # callbacks over the torch group otherwise (gloo rehearsals) or when RCCL cannot be opened
+        if args.transport == "host" or (args.transport == "auto" and backend != "nccl"):
+            comm = D.Comm.host()
+        else:
+            try:
+                comm = D.Comm.rccl()
+            except T.TreeeError as e:
+                if args.transport == "rccl":
+                    raise
+                print(f"# rank {rank}: RCCL transport unavailable ({e}); host-staged transport instead", file=sys.stderr)
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must use the same transport
+            if int(ok.item()) == 0:
+                comm = D.Comm.host()
 
     def step(record):
         nonlocal halo
-        if world > 1:
-            if state.get("gx") is None:
-                state["gx"] = D.GhostExchanger(pts, bounds, halo, rank, world, ctx=ctx)
-            cloud = stages.run("ghost_allgather", lambda: state["gx"].exchange(halo), record)
-        else:
-            cloud = pts
-        m = cloud.shape[0]
         free_state()  # previous step's handles: blocks return to the context pool, stream-ordered, no sync
+        if world > 1:
+            return step_sharded(record)
         # ONE Morton sort per step, two consumers: the kNN structure (its own Hilbert re-sort + box tree) is built on this
         # stream while the octree's node table -- ~50 small dependent launches -- is completed on a second one
         # (treee_sort_dev / treee_knn_from_octree_dev / treee_octree_complete_dev); --no-overlap builds them one after the other
         if overlap:
             def both():
-                o = T.Octree(cloud, ctx=ctx, defer=True)
+                o = T.Octree(pts, ctx=ctx, defer=True)
                 t = T.KDTree.from_octree(o, ctx)
                 o.complete(ctx2)
                 torch.cuda.current_stream().wait_stream(side)
                 return o, t
 
-            oc, tree_early = stages.run("keys_sort_octree_knn_structure", both, record)
+            oc, tree = stages.run("keys_sort_octree_knn_structure", both, record)
         else:
-            oc = stages.run("keys_sort_octree", lambda: T.Octree(cloud, ctx=ctx), record)
-        pending = None
-        if world > 1:
-            # The environment culls nothing (min 0, max u32::MAX), so the packed (depth, index) frame depends on
-            # positions only: draw it now and let RCCL min-reduce it on its own stream UNDER the kNN kernel; the
-            # values are looked up by the resolve pass once the curvature exists.
-            def draw():
-                T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj),
-                                                     env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, rank * n, None, None))
-                return D.reduce_packed_min_async(packed)
-
-            pending = stages.run("splat", draw, record)
-        tree = tree_early if overlap else stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
-        cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
-        # at N > 1 only the shard's own points are queried: the ghosts behind them are neighbours, not queries
-        stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv, n_own=n if world > 1 else None), record)
-        val = stages.run("map_to_u32", lambda: T.map_to_u32_dev(cv[:n], ctx), record)
+            oc = stages.run("keys_sort_octree", lambda: T.Octree(pts, ctx=ctx), record)
+            tree = stages.run("knn_build", lambda: T.KDTree.from_octree(oc, ctx), record)
+        cv = curve[:n]
+        stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv), record)
+        val = stages.run("map_to_u32", lambda: T.map_to_u32_dev(cv, ctx), record)
 
         def splat():
             T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), T.context.ptr(val), n, T.context.ptr(view), T.context.ptr(proj),
@@ -168,14 +182,42 @@ def main():
             T._lib.check(T.lib().treee_splat_resolve_dev(ctx.handle, T.context.ptr(packed), T.context.ptr(val), n, W, H, T.context.ptr(depth),
                                                          T.context.ptr(ids)))
 
+        stages.run("splat", splat, record)
+        state["oc"], state["tree"], state["curve"], state["cloud_n"] = oc, tree, cv, n
+        return oc, tree
+
+    def step_sharded(record):
+        if state.get("gx") is None:
+            state["gx"] = D.GhostExchanger(pts, bounds, halo, rank, world, ctx=ctx, comm=comm)
+        cloud = stages.run("ghost_allgather", lambda: state["gx"].exchange(halo), record)
+        m = cloud.shape[0]
+        # the rank's piece of the whole cloud's octree: own points only (ghosts are neighbours, not nodes)
+        oc = stages.run("sharded_octree", lambda: T.ShardedOctree(pts, comm, ctx=ctx), record)
+        state["owned"] = int(oc.rank_info.count)
+
+        # The environment culls nothing (min 0, max u32::MAX), so the packed (depth, index) frame depends on positions
+        # only: it is drawn now on the second stream and min-reduced there (RCCL: on that stream, under the kNN kernel of
+        # the first); the values are looked up by the resolve pass once the curvature exists.
+        def draw():
+            side.wait_stream(torch.cuda.current_stream())
+            T._lib.check(T.lib().treee_splat_dev(ctx2.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj),
+                                                 env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, rank * n, None, None))
+            D.frame_reduce_min(packed, comm, ctx2)
+
+        stages.run("splat_and_frame_reduce_enqueue", draw, record)
+        tree = stages.run("knn_build", lambda: T.KDTree.new(cloud, ctx), record)
+        cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
+        # only the shard's own points are queried: the ghosts behind them are neighbours, not queries
+        stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv, n_own=n), record)
+        val = stages.run("map_to_u32", lambda: T.map_to_u32_dev(cv[:n], ctx), record)
+
         def resolve():
-            pending.wait()
+            torch.cuda.current_stream().wait_stream(side)
+            # (the reduced frame's indices are global: rank * n + local; this rank resolves its own winners' values and
+            # leaves the others' -- the id plane of the whole frame is the union over the ranks)
             T._lib.check(T.lib().treee_splat_resolve_dev(ctx.handle, T.context.ptr(packed), T.context.ptr(val), n, W, H, T.context.ptr(depth), None))
 
-        if world > 1:
-            stages.run("frame_reduce_wait_resolve", resolve, record)
-        else:
-            stages.run("splat", splat, record)
+        stages.run("frame_reduce_wait_resolve", resolve, record)
         state["oc"], state["tree"], state["curve"], state["cloud_n"] = oc, tree, cv, m
         return oc, tree
 
@@ -242,7 +284,7 @@ def main():
             if name not in stage_roof:
                 stage_roof[name] = {"ms": round(ms[name], 3)}
         out = {
-            "metric": "Mpoints/s octree+kNN+splat (15M-point synthetic forest per GPU)",
+            "metric": f"Mpoints/s octree+kNN+splat ({n * world // 1_000_000}M-point synthetic forest, {n // 1_000_000}M per GPU)",
             "value": round(value, 3),
             "unit": "Mpoints/s",
             "n_gpus": world,
@@ -250,7 +292,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_points else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -259,7 +301,10 @@ def main():
                 "points_per_gpu": n,
                 "k": K,
                 "framebuffer": [W, H],
-                "parallelism": f"spatial x/z tiles {D.tile_grid(world)[0]}x{D.tile_grid(world)[1]}, ghost all-gather halo {halo} m",
+                "parallelism": f"spatial x/z tiles {D.tile_grid(world)[0]}x{D.tile_grid(world)[1]}, ghost all-gather halo {halo} m; sharded octree (common cube, "
+                               f"Morton-cell ownership: rank 0 holds {n} points and owns {state.get('owned')} of the sorted order)" if world > 1 else "one GPU",
+                "transport": None if comm is None else ("rccl" if comm.is_rccl else "host-staged callbacks over the torch group"),
+                "total_points": n * world,
                 "halo_verified": halo_verified,
             },
             "roofline": {
