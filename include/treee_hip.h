@@ -250,6 +250,15 @@ int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz_aos, const uint32_t *
                         uint32_t vmax, uint32_t w, uint32_t h, uint64_t *d_packed,
                         int32_t accumulate, uint32_t index_base, float *d_depth_out,
                         uint32_t *d_id_out);
+/* The same draw from the Morton-sorted records an octree handle already holds (TREEE_OCT_SORTED_XYZ) instead of the
+ * caller's cloud: one 16-byte load per point, and points that are neighbours in space are drawn by neighbouring lanes.
+ * The frame is bit for bit the one treee_splat_dev gives for the cloud the octree was built from: the packed word carries
+ * the point's ORIGINAL index, so equal depths still resolve to the smallest original index ("first drawn wins",
+ * render/src/point_cloud.rs:76-82) and d_value / the id buffer are indexed as before.  For a rank's piece of a sharded
+ * octree the indices are global: pass index_base = 0, and a d_value indexed globally (or NULL). */
+int32_t treee_splat_octree_dev(treee_ctx *ctx, const treee_octree *o, const uint32_t *d_value, const float view[16],
+                               const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h,
+                               uint64_t *d_packed, int32_t accumulate, uint32_t index_base, float *d_depth, uint32_t *d_id_out);
 /* resolve a packed buffer (after a cross-GPU min) into depth + id; d_value indexes by the
  * low 32 bits */
 int32_t treee_splat_resolve_dev(treee_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_value,

@@ -477,6 +477,42 @@ def test_splat_value_cull_ties_and_device_path(T, oracle):
         T.PointCloud(pts).render(T.PointCloudProperty(val), view, bad, env, w, h)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_splat_from_the_octrees_sorted_records_is_the_same_frame(T, oracle, seed):
+    """treee_splat_octree_dev: drawing the Morton-sorted records changes the order points are drawn in, not the frame --
+    the depth test keeps the nearest splat and, on equal depth, the smallest ORIGINAL index (point_cloud.rs:76-82): value
+    culling, coincident points, huge splats, packed output with an index base."""
+    import torch
+
+    from treee_amd import synth
+
+    rng = np.random.default_rng(500 + seed)
+    pts, seg = synth.forest_cloud(int(rng.choice([3, 5000, 120_000])), plot=float(rng.choice([6.0, 25.0])))
+    pts = np.concatenate([pts, pts[: len(pts) // 2]])  # coincident points: equal depths, the lower index must win
+    val = rng.integers(0, 2**32, len(pts), dtype=np.uint64).astype(np.uint32)
+    d_pts, d_val = torch.from_numpy(pts).cuda(), torch.from_numpy(val.view(np.int32)).cuda()
+    oc = T.Octree(d_pts)
+    cloud, prop = T.PointCloud(d_pts), T.PointCloudProperty(d_val)
+    for _ in range(3):
+        w, h = int(rng.integers(8, 300)), int(rng.integers(8, 200))
+        tf = T.rotation_x(float(rng.uniform(-1.5, 0.2))) @ T.translation(float(rng.uniform(-3, 3)), float(rng.uniform(0, 8)), float(rng.uniform(0.5, 60)))
+        view, proj = T.view_from_transform(tf.astype(np.float32)), T.Camera3D(w / h).projection()
+        vmin, vmax = (0, 0xFFFFFFFF) if rng.random() < 0.5 else (int(rng.integers(0, 2**31)), int(rng.integers(2**31, 2**32)))
+        env = T.PointCloudEnvironment(vmin, vmax, float(rng.choice([0.05, 0.4, 2.5])))
+        a = cloud.render(prop, view, proj, env, w, h)
+        b = cloud.render(prop, view, proj, env, w, h, octree=oc)
+        assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[1], b[1])
+        rd, ri, _ = oracle.splat(pts, val, view, proj, env.scale, vmin, vmax, w, h)
+        assert np.array_equal(b[0].cpu().numpy().view(np.uint32), rd.view(np.uint32)) and np.array_equal(b[1].cpu().numpy().view(np.uint32), ri)
+    # packed output with an index base (multi-chunk / multi-GPU draws)
+    ctx = T.default_context(torch.device("cuda", 0))
+    pa, pb = torch.empty((h, w), dtype=torch.int64, device="cuda"), torch.empty((h, w), dtype=torch.int64, device="cuda")
+    ptr = T.context.ptr
+    T._lib.check(T.lib().treee_splat_dev(ctx.handle, ptr(d_pts), None, len(pts), ptr(view), ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h, ptr(pa), 0, 1000, None, None))
+    T._lib.check(T.lib().treee_splat_octree_dev(ctx.handle, oc._h, None, ptr(view), ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h, ptr(pb), 0, 1000, None, None))
+    assert torch.equal(pa, pb)
+
+
 def test_splat_without_values_when_nothing_is_culled(T):
     """the packed (depth, index) frame depends on positions only when the environment culls nothing: drawing with
     d_value = NULL gives the same frame; with a culling range it is refused"""
@@ -637,7 +673,10 @@ def test_full_size_15m_splat_bit_exact(T, oracle):
     w, h = 1920, 1080
     proj = T.Camera3D(w / h).projection()
     env = T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+    import torch
+
     cloud, prop = T.PointCloud(d_pts), T.PointCloudProperty(d_seg)
+    oc = T.Octree(d_pts)
     for tf in (T.translation(0.0, 0.0, 100.0), T.rotation_x(-np.pi / 2) @ T.translation(0.0, 0.0, 300.0)):
         view = T.view_from_transform(tf.astype(np.float32))
         depth, ids = cloud.render(prop, view, proj, env, w, h)
@@ -645,6 +684,8 @@ def test_full_size_15m_splat_bit_exact(T, oracle):
         assert np.array_equal(depth.cpu().numpy().view(np.uint32), rd.view(np.uint32))
         assert np.array_equal(ids.cpu().numpy().view(np.uint32), ri)
         assert int((rd < 1.0).sum()) > 50_000
+        d2, i2 = cloud.render(prop, view, proj, env, w, h, octree=oc)  # drawn from the octree's sorted records: the same frame
+        assert torch.equal(d2.view(torch.int32), depth.view(torch.int32)) and torch.equal(i2, ids)
 
 
 def test_config0_uniform_1m_knn_and_curve_vs_reference_kdtree(T, oracle):

@@ -147,10 +147,12 @@ struct HostComm final : treee_comm {
 		} catch (const std::exception &) {
 			return set_err(TREEE_ERR_NOMEM, "host transport: staging buffer");
 		}
-		if (s_end) TREEE_HIP(hipMemcpyAsync(a.data(), d_send, s_end, hipMemcpyDeviceToHost, ctx->stream));
+		for (int r = 0; r < world; ++r) // (only what is sent: the send buffer is the rank's whole sorted cloud)
+			if (send_bytes[r]) TREEE_HIP(hipMemcpyAsync(a.data() + send_off[r], (const char *)d_send + send_off[r], send_bytes[r], hipMemcpyDeviceToHost, ctx->stream));
 		TREEE_HIP(hipStreamSynchronize(ctx->stream));
 		TREEE_TRY(call(ops.all_to_all_v(ops.user, a.data(), send_off, send_bytes, b.data(), recv_off, recv_bytes), "all_to_all_v"));
-		if (r_end) TREEE_HIP(hipMemcpyAsync(d_recv, b.data(), r_end, hipMemcpyHostToDevice, ctx->stream));
+		for (int r = 0; r < world; ++r)
+			if (recv_bytes[r]) TREEE_HIP(hipMemcpyAsync((char *)d_recv + recv_off[r], b.data() + recv_off[r], recv_bytes[r], hipMemcpyHostToDevice, ctx->stream));
 		TREEE_HIP(hipStreamSynchronize(ctx->stream));
 		return TREEE_OK;
 	}

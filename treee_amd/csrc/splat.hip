@@ -82,18 +82,40 @@ __global__ __launch_bounds__(256) void k_splat_clear(unsigned long long *packed,
 	if (i < count) packed[i] = PACKED_CLEAR;
 }
 
-__global__ __launch_bounds__(256) void k_splat_points(const float *__restrict__ xyz, const uint32_t *__restrict__ value, uint32_t n,
+// REC = false: the caller's cloud, float xyz[n][3] (the layout of &[Point3<f32>]), index = position.
+// REC = true: the records an octree already holds in Morton order, float4 (x, y, z, bitcast(original index)): one 16-byte
+// load per lane instead of three strided 4-byte ones, and neighbouring lanes draw neighbouring pixels (their atomics meet
+// in the same L2 lines).  The packed word carries the ORIGINAL index either way, so "first drawn wins" still means the
+// smallest original index (render/src/point_cloud.rs:76-82) and the frame does not depend on the order points are drawn in.
+template <bool REC> __device__ __forceinline__ bool load_point(const void *__restrict__ pts, const uint32_t *__restrict__ value, bool use_value, uint32_t i,
+                                                              const SplatParams &P, Foot &f, uint32_t &orig) {
+	float x, y, z;
+	if (REC) {
+		const float4 p = ((const float4 *)pts)[i];
+		x = p.x, y = p.y, z = p.z;
+		orig = __float_as_uint(p.w);
+	} else {
+		const float *xyz = (const float *)pts;
+		x = xyz[3ull * i + 0], y = xyz[3ull * i + 1], z = xyz[3ull * i + 2];
+		orig = i;
+	}
+	return footprint(P, x, y, z, use_value ? value[orig] : P.vmin, f); // (nothing culled: the values are not read at all)
+}
+
+template <bool REC>
+__global__ __launch_bounds__(256) void k_splat_points(const void *__restrict__ pts, const uint32_t *__restrict__ value, bool use_value, uint32_t n,
                                                        SplatParams P, unsigned long long *packed,
                                                        uint32_t *__restrict__ large_count, uint32_t *__restrict__ large_list) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	Foot f;
-	if (!footprint(P, xyz[3ull * i + 0], xyz[3ull * i + 1], xyz[3ull * i + 2], value ? value[i] : P.vmin, f)) return;
+	uint32_t orig;
+	if (!load_point<REC>(pts, value, use_value, i, P, f, orig)) return;
 	if ((f.x1 - f.x0) * (f.y1 - f.y0) > LARGE_AREA) {
 		large_list[atomicAdd(large_count, 1u)] = i;
 		return;
 	}
-	const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + i);
+	const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + orig);
 	for (int py = f.y0; py < f.y1; ++py) {
 		const float v = row_v(f, py);
 		if (!(v * v < 1.0f)) continue; // (u * u >= 0: no pixel of this row can pass; NaN rows never pass either)
@@ -101,15 +123,17 @@ __global__ __launch_bounds__(256) void k_splat_points(const float *__restrict__ 
 	}
 }
 
-__global__ __launch_bounds__(256) void k_splat_large(const float *__restrict__ xyz, const uint32_t *__restrict__ value,
+template <bool REC>
+__global__ __launch_bounds__(256) void k_splat_large(const void *__restrict__ pts, const uint32_t *__restrict__ value, bool use_value,
                                                       SplatParams P, unsigned long long *packed,
                                                       const uint32_t *__restrict__ large_count, const uint32_t *__restrict__ large_list) {
 	const uint32_t total = *large_count;
 	for (uint32_t s = blockIdx.x; s < total; s += gridDim.x) {
 		const uint32_t i = large_list[s];
 		Foot f;
-		if (!footprint(P, xyz[3ull * i + 0], xyz[3ull * i + 1], xyz[3ull * i + 2], value ? value[i] : P.vmin, f)) continue;
-		const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + i);
+		uint32_t orig;
+		if (!load_point<REC>(pts, value, use_value, i, P, f, orig)) continue;
+		const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + orig);
 		const int bw = f.x1 - f.x0;
 		const int area = bw * (f.y1 - f.y0);
 		for (int t = threadIdx.x; t < area; t += 256) plot(packed, P.w, f, f.x0 + t % bw, f.y0 + t / bw, row_v(f, f.y0 + t / bw), mine);
@@ -205,14 +229,14 @@ int32_t check_proj(const float proj[16]) {
 
 extern "C" {
 
-int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_value, uint64_t n, const float view[16],
-                        const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h,
-                        uint64_t *d_packed, int32_t accumulate, uint32_t index_base, float *d_depth, uint32_t *d_id) {
-	if (!ctx || !view || !proj || (n && !d_xyz)) return set_err(TREEE_ERR_INVALID, "treee_splat_dev: null argument");
+// pts: float xyz[n][3] (rec = false) or float4 records in any order whose .w is the point's index into d_value (rec = true)
+static int32_t splat_any(treee_ctx *ctx, const void *d_pts, bool rec, const uint32_t *d_value, uint64_t n, uint64_t n_values, const float view[16],
+                         const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h, uint64_t *d_packed,
+                         int32_t accumulate, uint32_t index_base, float *d_depth, uint32_t *d_id) {
 	if (n && !d_value && (vmin != 0u || vmax != 0xFFFFFFFFu || d_id))
 		return set_err(TREEE_ERR_INVALID, "treee_splat_dev: d_value may only be null when nothing is culled (vmin = 0, vmax = u32::MAX) and no id buffer is asked for");
 	if (w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 31)) return set_err(TREEE_ERR_INVALID, "bad framebuffer size %ux%u", w, h);
-	if (n >= 0xFFFFFFFFull - index_base) return set_err(TREEE_ERR_UNSUPPORTED, "point index does not fit in 32 bits");
+	if (n_values >= 0xFFFFFFFFull - index_base) return set_err(TREEE_ERR_UNSUPPORTED, "point index does not fit in 32 bits");
 	if (index_base != 0 && d_id)
 		return set_err(TREEE_ERR_INVALID, "d_id_out needs index_base == 0; resolve multi-chunk draws with treee_splat_resolve_dev");
 	TREEE_TRY(check_proj(proj));
@@ -240,13 +264,39 @@ int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_va
 		TREEE_TRY(ctx->alloc_t(1, &d_lc));
 		TREEE_TRY(ctx->alloc_t(n, &d_ll));
 		TREEE_HIP(hipMemsetAsync(d_lc, 0, 4, st));
-		hipLaunchKernelGGL(k_splat_points, dim3(div_up(n, 256)), dim3(256), 0, st, d_xyz, d_value, (uint32_t)n, P, packed, d_lc, d_ll);
-		hipLaunchKernelGGL(k_splat_large, dim3(ctx->num_cus * 4), dim3(256), 0, st, d_xyz, d_value, P, packed, d_lc, d_ll);
+		const bool use_value = d_value && !(vmin == 0u && vmax == 0xFFFFFFFFu); // the cull of point_cloud.wgsl:44-49 can never fire otherwise
+		if (rec) {
+			hipLaunchKernelGGL(k_splat_points<true>, dim3(div_up(n, 256)), dim3(256), 0, st, d_pts, d_value, use_value, (uint32_t)n, P, packed, d_lc, d_ll);
+			hipLaunchKernelGGL(k_splat_large<true>, dim3(ctx->num_cus * 4), dim3(256), 0, st, d_pts, d_value, use_value, P, packed, d_lc, d_ll);
+		} else {
+			hipLaunchKernelGGL(k_splat_points<false>, dim3(div_up(n, 256)), dim3(256), 0, st, d_pts, d_value, use_value, (uint32_t)n, P, packed, d_lc, d_ll);
+			hipLaunchKernelGGL(k_splat_large<false>, dim3(ctx->num_cus * 4), dim3(256), 0, st, d_pts, d_value, use_value, P, packed, d_lc, d_ll);
+		}
 	}
 	if (d_depth || d_id)
-		hipLaunchKernelGGL(k_splat_resolve, dim3(div_up(px, 256)), dim3(256), 0, st, packed, d_value, (uint32_t)n, px, d_depth, d_id);
+		hipLaunchKernelGGL(k_splat_resolve, dim3(div_up(px, 256)), dim3(256), 0, st, packed, d_value, (uint32_t)n_values, px, d_depth, d_id);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
+}
+
+int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_value, uint64_t n, const float view[16],
+                        const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h,
+                        uint64_t *d_packed, int32_t accumulate, uint32_t index_base, float *d_depth, uint32_t *d_id) {
+	if (!ctx || !view || !proj || (n && !d_xyz)) return set_err(TREEE_ERR_INVALID, "treee_splat_dev: null argument");
+	return splat_any(ctx, d_xyz, false, d_value, n, n, view, proj, scale, vmin, vmax, w, h, d_packed, accumulate, index_base, d_depth, d_id);
+}
+
+int32_t treee_splat_octree_dev(treee_ctx *ctx, const treee_octree *o, const uint32_t *d_value, const float view[16], const float proj[16],
+                               float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h, uint64_t *d_packed, int32_t accumulate,
+                               uint32_t index_base, float *d_depth, uint32_t *d_id) {
+	if (!ctx || !o || !view || !proj) return set_err(TREEE_ERR_INVALID, "treee_splat_octree_dev: null argument");
+	std::shared_ptr<SortedCloud> sc = octree_sorted_cloud(o);
+	if (sc->device != ctx->device) return set_err(TREEE_ERR_INVALID, "treee_splat_octree_dev: context of another device");
+	TREEE_TRY(use_begin(ctx, sc->owner, &sc->sync));
+	const int32_t rc = splat_any(ctx, sc->d_sorted, true, d_value, sc->n, octree_is_shard(o) ? 0xFFFFFFFEull - index_base : sc->n, view, proj, scale, vmin, vmax,
+	                             w, h, d_packed, accumulate, index_base, d_depth, d_id);
+	const int32_t e = use_end(ctx, sc->owner, &sc->sync);
+	return rc != TREEE_OK ? rc : e;
 }
 
 int32_t treee_splat_resolve_dev(treee_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_value, uint64_t n_values, uint32_t w,

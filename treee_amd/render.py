@@ -72,8 +72,9 @@ class PointCloud:
         self.buffer = dev_f32(vertices, 3) if is_device(vertices) else host_f32(vertices, 3)
         self.instances = int(self.buffer.shape[0])
 
-    def render(self, property, view, proj, environment, width, height, ctx=None):
-        """one draw of all instances; returns (depth[h,w] f32, id[h,w] u32)."""
+    def render(self, property, view, proj, environment, width, height, ctx=None, octree=None):
+        """one draw of all instances; returns (depth[h,w] f32, id[h,w] u32).  `octree` (an Octree built from these very
+        vertices): draw from its Morton-sorted records instead (treee_splat_octree_dev) -- the same frame, bit for bit."""
         if property.length != 0:
             assert property.length == self.instances, f"{property.length} {self.instances}"  # point_cloud.rs:161-167
         view = host_f32(view).reshape(16)
@@ -85,6 +86,11 @@ class PointCloud:
             c = ctx or default_context(self.buffer.device)
             depth = torch.empty((height, width), dtype=torch.float32, device=self.buffer.device)
             ids = torch.empty((height, width), dtype=torch.int32, device=self.buffer.device)
+            if octree is not None:
+                assert octree.n_points == self.instances
+                _lib.check(_lib.lib().treee_splat_octree_dev(c.handle, octree._h, ptr(property.data), ptr(view), ptr(proj), env.scale, env.min, env.max,
+                                                             width, height, None, 0, 0, ptr(depth), ptr(ids)))
+                return depth, ids
             _lib.check(
                 _lib.lib().treee_splat_dev(
                     c.handle, ptr(self.buffer), ptr(property.data), self.instances, ptr(view), ptr(proj), env.scale, env.min, env.max,
