@@ -15,6 +15,8 @@
 // workgroup-per-splat kernel so one lane never serialises a huge disc.
 #include "common.h"
 
+#include <cstdlib>
+
 using namespace treee;
 
 namespace {
@@ -120,6 +122,79 @@ __global__ __launch_bounds__(256) void k_splat_points(const void *__restrict__ p
 		const float v = row_v(f, py);
 		if (!(v * v < 1.0f)) continue; // (u * u >= 0: no pixel of this row can pass; NaN rows never pass either)
 		for (int px = f.x0; px < f.x1; ++px) plot(packed, P.w, f, px, py, v, mine);
+	}
+}
+
+// The sorted records once more, with the depth test done in LDS first (cdna_hip_programming.md, Guideline 12: reduce in
+// the workgroup, then one global atomic per destination).  256 Morton-consecutive points are a compact blob in space and,
+// unless the camera sits inside it, a few dozen pixels on the screen: the workgroup takes the bounding box of its
+// footprints, resolves all fragments that fall in it with ds_min_u64 on a tile of at most TILE_PX pixels, and sends one
+// plain-load test + atomicMin per TOUCHED PIXEL to the frame -- instead of one per fragment, which is what makes drawing
+// in sorted order slower than drawing in input order (same-pixel atomics of neighbouring lanes serialise at the memory
+// side).  A workgroup whose box is larger draws the ordinary way.  min over (depth, original index) is order-free: the
+// frame is the same, bit for bit.
+constexpr int TILE_PX = 1024;
+__global__ __launch_bounds__(256) void k_splat_tile(const float4 *__restrict__ rec, const uint32_t *__restrict__ value, bool use_value, uint32_t n,
+                                                     SplatParams P, unsigned long long *packed, uint32_t *__restrict__ large_count,
+                                                     uint32_t *__restrict__ large_list) {
+	__shared__ unsigned long long s_tile[TILE_PX];
+	__shared__ int s_box[4][4];
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	Foot f;
+	uint32_t orig = 0;
+	bool draw = i < n && load_point<true>(rec, value, use_value, i, P, f, orig);
+	if (draw && (f.x1 - f.x0) * (f.y1 - f.y0) > LARGE_AREA) {
+		large_list[atomicAdd(large_count, 1u)] = i;
+		draw = false;
+	}
+	int bx0 = draw ? f.x0 : 0x7FFFFFFF, by0 = draw ? f.y0 : 0x7FFFFFFF, bx1 = draw ? f.x1 : -1, by1 = draw ? f.y1 : -1;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		bx0 = min(bx0, __shfl_xor(bx0, o, 64));
+		by0 = min(by0, __shfl_xor(by0, o, 64));
+		bx1 = max(bx1, __shfl_xor(bx1, o, 64));
+		by1 = max(by1, __shfl_xor(by1, o, 64));
+	}
+	if ((threadIdx.x & 63u) == 0) {
+		int *b = s_box[threadIdx.x >> 6];
+		b[0] = bx0, b[1] = by0, b[2] = bx1, b[3] = by1;
+	}
+	__syncthreads();
+	bx0 = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
+	by0 = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
+	bx1 = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
+	by1 = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
+	if (bx1 <= bx0) return; // nothing to draw (uniform)
+	const int bw = bx1 - bx0, area = bw * (by1 - by0);
+	const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + orig);
+	if (area > TILE_PX) { // (uniform) a box too large for the tile: fragment by fragment, as k_splat_points does
+		if (!draw) return;
+		for (int py = f.y0; py < f.y1; ++py) {
+			const float v = row_v(f, py);
+			if (!(v * v < 1.0f)) continue;
+			for (int px = f.x0; px < f.x1; ++px) plot(packed, P.w, f, px, py, v, mine);
+		}
+		return;
+	}
+	for (int t = threadIdx.x; t < area; t += 256) s_tile[t] = PACKED_CLEAR;
+	__syncthreads();
+	if (draw)
+		for (int py = f.y0; py < f.y1; ++py) {
+			const float v = row_v(f, py);
+			if (!(v * v < 1.0f)) continue;
+			for (int px = f.x0; px < f.x1; ++px) {
+				const float u = (((float)px + 0.5f) - f.sx) / f.rx;
+				if (!(u * u + v * v < 1.0f)) continue; // point_cloud.wgsl:74-76
+				unsigned long long *q = &s_tile[(py - by0) * bw + (px - bx0)];
+				if (mine < *q) atomicMin(q, mine);
+			}
+		}
+	__syncthreads();
+	for (int t = threadIdx.x; t < area; t += 256) {
+		const unsigned long long best = s_tile[t];
+		if (best == PACKED_CLEAR) continue;
+		unsigned long long *q = packed + (size_t)(by0 + t / bw) * P.w + (bx0 + t % bw);
+		if (best < *q) atomicMin(q, best);
 	}
 }
 
@@ -266,7 +341,11 @@ static int32_t splat_any(treee_ctx *ctx, const void *d_pts, bool rec, const uint
 		TREEE_HIP(hipMemsetAsync(d_lc, 0, 4, st));
 		const bool use_value = d_value && !(vmin == 0u && vmax == 0xFFFFFFFFu); // the cull of point_cloud.wgsl:44-49 can never fire otherwise
 		if (rec) {
-			hipLaunchKernelGGL(k_splat_points<true>, dim3(div_up(n, 256)), dim3(256), 0, st, d_pts, d_value, use_value, (uint32_t)n, P, packed, d_lc, d_ll);
+			static const bool no_tile = getenv("TREEE_SPLAT_NO_TILE") != nullptr; // A/B hook: fragment-by-fragment global atomics
+			if (no_tile)
+				hipLaunchKernelGGL(k_splat_points<true>, dim3(div_up(n, 256)), dim3(256), 0, st, d_pts, d_value, use_value, (uint32_t)n, P, packed, d_lc, d_ll);
+			else
+				hipLaunchKernelGGL(k_splat_tile, dim3(div_up(n, 256)), dim3(256), 0, st, (const float4 *)d_pts, d_value, use_value, (uint32_t)n, P, packed, d_lc, d_ll);
 			hipLaunchKernelGGL(k_splat_large<true>, dim3(ctx->num_cus * 4), dim3(256), 0, st, d_pts, d_value, use_value, P, packed, d_lc, d_ll);
 		} else {
 			hipLaunchKernelGGL(k_splat_points<false>, dim3(div_up(n, 256)), dim3(256), 0, st, d_pts, d_value, use_value, (uint32_t)n, P, packed, d_lc, d_ll);
