@@ -55,9 +55,8 @@ def parse():
                     "host callbacks over the torch group")
     ap.add_argument("--plot", type=float, default=PLOT, help="edge of the square tile in metres (632 with --points 150000000 keeps the density)")
     ap.add_argument("--halo", type=float, default=2.0)
-    ap.add_argument("--splat-sorted", action="store_true", help="draw the octree's Morton-sorted records (treee_splat_octree_dev) instead of the caller's "
-                    "cloud: same frame; measured SLOWER at this density (0.43 vs 0.31 ms: neighbouring lanes then hit the same pixels and their "
-                    "atomics serialise), so it is not the default")
+    ap.add_argument("--splat-unsorted", action="store_true", help="draw the caller's cloud fragment by fragment (treee_splat_dev, rounds 1-2) instead of the "
+                    "octree's Morton-sorted records through the per-workgroup LDS tile (treee_splat_octree_dev): same frame, 0.31 vs 0.20 ms")
     ap.add_argument("--no-overlap", action="store_true", help="build the octree's node table and the kNN structure one after the other on one stream")
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="points of the CPU-baseline sample (about 10-30 s of oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,8 +179,9 @@ def main():
         val = stages.run("map_to_u32", lambda: T.map_to_u32_dev(cv, ctx), record)
 
         def splat():
-            # --splat-sorted draws the octree's Morton-sorted records (one 16-byte load per point); same frame either way
-            if not args.splat_sorted:
+            # the octree's Morton-sorted records (one 16-byte load per point), resolved in an LDS tile per workgroup before
+            # the frame's atomics; --splat-unsorted draws the caller's cloud as in rounds 1-2.  Same frame either way.
+            if args.splat_unsorted:
                 T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), T.context.ptr(val), n, T.context.ptr(view), T.context.ptr(proj),
                                                      env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, 0, None, None))
             else:
