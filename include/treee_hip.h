@@ -152,7 +152,7 @@ int32_t treee_map_to_u32_dev(treee_ctx *ctx, const float *d_in, uint64_t n, uint
 /* segmentation (treee/src/segmenting.rs:110-235) with TreeSet::new / add_point / filter_trees / tree_positions (:419-524),
  * Tree (:242-396) and centroid (:526-545): 1 m height slices top-down, per slice the convex areas grown from its points,
  * matched to the centroids handed down from the slice above, Voronoi cells of the centroids clipped to the box
- * [bbox_min_xz, bbox_max_xz] (the loaded cloud's min / max in x and z), every point assigned to the first cell that
+ * [bbox_min_xz, bbox_max_xz] (the loaded cloud's min / max in x and z; both NULL: taken from the points), every point assigned to the first cell that
  * contains it with 0.1 slack (move-to-front order).  segment_out[i] = id of point i, 0 = none (DELETED_INDEX);
  * *n_segments_out = largest id + 1.  The reference's run is random (thread_rng shuffle, RandomState map order, random
  * ids) and its Voronoi cells come from a third-party crate absent from the snapshot: this is the deterministic variant

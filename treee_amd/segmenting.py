@@ -17,11 +17,14 @@ def segment_slices(points, bbox_min=None, bbox_max=None, max_distance=DEFAULT_MA
     """-> (segment u32[n], n_segments).  `bbox_min` / `bbox_max`: the loaded cloud's min / max (x, y, z) as `Loading` keeps
     them (loading.rs:16-17; default: of `points`); only x and z are used (segmenting.rs:148-154)."""
     p = host_f32(points, 3)
-    lo = p.min(0) if bbox_min is None and len(p) else np.zeros(3, np.float32) if bbox_min is None else np.asarray(bbox_min, np.float32)
-    hi = p.max(0) if bbox_max is None and len(p) else np.zeros(3, np.float32) if bbox_max is None else np.asarray(bbox_max, np.float32)
-    bmin = np.ascontiguousarray([lo[0], lo[2]], dtype=np.float32)
-    bmax = np.ascontiguousarray([hi[0], hi[2]], dtype=np.float32)
-    seg = np.zeros(len(p), np.uint32)
+    if bbox_min is None or bbox_max is None:  # the library takes the box from the points (numpy's min / max over 1.5 M rows cost a third of the call)
+        assert bbox_min is None and bbox_max is None
+        bmin = bmax = None
+    else:
+        lo, hi = np.asarray(bbox_min, np.float32), np.asarray(bbox_max, np.float32)
+        bmin = np.ascontiguousarray([lo[0], lo[2]], dtype=np.float32)
+        bmax = np.ascontiguousarray([hi[0], hi[2]], dtype=np.float32)
+    seg = np.empty(len(p), np.uint32)
     nseg = C.c_uint32(0)
     _lib.check(_lib.lib().treee_segment_slices(ptr(p), len(p), ptr(bmin), ptr(bmax), float(max_distance), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(seg),
                                                C.byref(nseg)))
