@@ -414,32 +414,56 @@ constexpr size_t MAX_LAYERS = size_t(1) << 20; // 1 m layers: a cloud taller tha
 
 int32_t segment_slices(const float *xyz, uint64_t n, const float *bbox_min_xz, const float *bbox_max_xz, float max_distance, uint64_t seed, uint32_t *segment_out,
                        uint32_t *n_segments_out) {
-	P2 bmin = {0.0f, 0.0f}, bmax = {0.0f, 0.0f};
-	if (bbox_min_xz && bbox_max_xz) {
-		bmin = {bbox_min_xz[0], bbox_min_xz[1]};
-		bmax = {bbox_max_xz[0], bbox_max_xz[1]};
-	} else if (n) { // the box `Loading` keeps (loading.rs:16-17), taken from the points themselves
-		bmin = {INFINITY, INFINITY};
-		bmax = {-INFINITY, -INFINITY};
-		for (uint64_t i = 0; i < n; ++i) {
-			bmin = {std::fmin(bmin.x, xyz[3 * i]), std::fmin(bmin.y, xyz[3 * i + 2])};
-			bmax = {std::fmax(bmax.x, xyz[3 * i]), std::fmax(bmax.y, xyz[3 * i + 2])};
-		}
-	}
 	// loading.rs:97-101 + segmenting.rs:121-133: 1 m layers of height, keyed floor(y), points in arrival order (a stable
-	// counting sort by key: the reference's HashMap<isize, Vec<Point>> densified top-down)
+	// counting sort by key: the reference's HashMap<isize, Vec<Point>> densified top-down).  One pass over the cloud, in
+	// pieces over the host's threads: every point's key, the key range, and the x / z box when the caller did not give it.
 	auto key_of = [&](uint64_t i) -> int64_t {
 		const float f = std::floor(xyz[3 * i + 1]);
 		return !(f == f) ? 0 : (f >= 9.2233720368547758e18f ? INT64_MAX : (f <= -9.2233720368547758e18f ? INT64_MIN : (int64_t)f)); // `as isize`
 	};
+	const bool own_box = !(bbox_min_xz && bbox_max_xz);
+	P2 bmin = {0.0f, 0.0f}, bmax = {0.0f, 0.0f};
+	if (!own_box) {
+		bmin = {bbox_min_xz[0], bbox_min_xz[1]};
+		bmax = {bbox_max_xz[0], bbox_max_xz[1]};
+	}
 	uint32_t next_id = 1;
 	const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 	if (n) {
+		std::vector<int64_t> key(n);
 		int64_t lo = INT64_MAX, hi = INT64_MIN;
-		for (uint64_t i = 0; i < n; ++i) {
-			const int64_t k = key_of(i);
-			lo = std::min(lo, k);
-			hi = std::max(hi, k);
+		{
+			const unsigned parts = std::max(1u, std::min(treee::host_threads(), (unsigned)(n / 65536 + 1)));
+			struct Part {
+				int64_t lo = INT64_MAX, hi = INT64_MIN;
+				P2 mn = {INFINITY, INFINITY}, mx = {-INFINITY, -INFINITY};
+			};
+			std::vector<Part> part(parts);
+			auto scan = [&](unsigned t) {
+				Part &pt = part[t];
+				for (uint64_t i = n * t / parts, e = n * (t + 1) / parts; i < e; ++i) {
+					const int64_t k = key[i] = key_of(i);
+					pt.lo = std::min(pt.lo, k);
+					pt.hi = std::max(pt.hi, k);
+					if (own_box) { // the box `Loading` keeps (loading.rs:16-17), taken from the points themselves
+						pt.mn = {std::fmin(pt.mn.x, xyz[3 * i]), std::fmin(pt.mn.y, xyz[3 * i + 2])};
+						pt.mx = {std::fmax(pt.mx.x, xyz[3 * i]), std::fmax(pt.mx.y, xyz[3 * i + 2])};
+					}
+				}
+			};
+			std::vector<std::thread> pool;
+			for (unsigned t = 1; t < parts; ++t) pool.emplace_back(scan, t);
+			scan(0);
+			for (auto &t : pool) t.join();
+			if (own_box) bmin = {INFINITY, INFINITY}, bmax = {-INFINITY, -INFINITY};
+			for (const Part &pt : part) {
+				lo = std::min(lo, pt.lo);
+				hi = std::max(hi, pt.hi);
+				if (own_box) {
+					bmin = {std::fmin(bmin.x, pt.mn.x), std::fmin(bmin.y, pt.mn.y)};
+					bmax = {std::fmax(bmax.x, pt.mx.x), std::fmax(bmax.y, pt.mx.y)};
+				}
+			}
 		}
 		if ((uint64_t)hi - (uint64_t)lo >= MAX_LAYERS)
 			return set_err(TREEE_ERR_UNSUPPORTED, "treee_segment_slices: the cloud spans %llu one-metre layers (y from %lld to %lld); more than %zu is refused",
@@ -453,9 +477,10 @@ int32_t segment_slices(const float *xyz, uint64_t n, const float *bbox_min_xz, c
 		std::vector<Layer> layer(layers); // layer[0] = top slice
 		{
 			std::vector<uint32_t> count(layers, 0);
-			for (uint64_t i = 0; i < n; ++i) ++count[(size_t)(hi - key_of(i))];
+			for (uint64_t i = 0; i < n; ++i) ++count[(size_t)(hi - key[i])];
 			for (size_t li = 0; li < layers; ++li) layer[li].order.reserve(count[li]);
-			for (uint64_t i = 0; i < n; ++i) layer[(size_t)(hi - key_of(i))].order.push_back((uint32_t)i);
+			for (uint64_t i = 0; i < n; ++i) layer[(size_t)(hi - key[i])].order.push_back((uint32_t)i);
+			std::vector<int64_t>().swap(key);
 		}
 		// The reference gives every slice to a rayon worker (:164-234): TreeSet::new needs nothing from the other slices, the
 		// centroids travel down a chain of channels (:135-146, :173-179), and the cells and the assignment of a slice need only
