@@ -260,6 +260,7 @@ int32_t mark_ready(treee_ctx *owner, HandleSync *hs);
 int32_t use_begin(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs);
 int32_t use_end(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs);
 void retire(treee_ctx *owner, HandleSync *hs);
+void wait_users(treee_ctx *owner, HandleSync *hs); // order the owner behind the uses so far without ending the handle's events
 
 // ---- internal stage entry points (device pointers, enqueue on ctx->stream) ---------------
 // radix_sort.hip

@@ -146,6 +146,14 @@ int32_t use_end(treee_ctx *ctx, treee_ctx *owner, HandleSync *hs) {
 	return TREEE_OK;
 }
 
+// the owner's stream waits for the uses recorded so far; the events and `ready` stay (the handle lives on)
+void wait_users(treee_ctx *owner, HandleSync *hs) {
+	std::lock_guard<std::mutex> lk(hs->mu);
+	if (!ctx_is_live(owner)) return;
+	for (auto &u : hs->users)
+		if (hipStreamWaitEvent(owner->stream, u.second, 0) != hipSuccess) (void)hipEventSynchronize(u.second);
+}
+
 void retire(treee_ctx *owner, HandleSync *hs) {
 	std::lock_guard<std::mutex> lk(hs->mu);
 	const bool live = ctx_is_live(owner);
@@ -198,10 +206,21 @@ int32_t default_ctx(treee_ctx **out) {
 using namespace treee;
 
 int32_t treee_ctx::fork() {
-	if (!aux) {
-		TREEE_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-		TREEE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-		TREEE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+	if (!aux) { // all three or none: a half-made set would leave later fork() / join() calls recording on a null event
+		hipStream_t s = nullptr;
+		hipEvent_t ef = nullptr, ej = nullptr;
+		hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&ef, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+		if (e != hipSuccess) {
+			if (ej) (void)hipEventDestroy(ej);
+			if (ef) (void)hipEventDestroy(ef);
+			if (s) (void)hipStreamDestroy(s);
+			return set_err(TREEE_ERR_HIP, "auxiliary stream of the context: %s", hipGetErrorString(e));
+		}
+		aux = s;
+		ev_fork = ef;
+		ev_join = ej;
 	}
 	TREEE_HIP(hipEventRecord(ev_fork, stream));
 	TREEE_HIP(hipStreamWaitEvent(aux, ev_fork, 0));

@@ -1693,10 +1693,11 @@ int32_t treee_knn_build(const float *xyz, uint64_t n, treee_knn **out) {
 int32_t treee_knn_free(treee_knn *t) {
 	if (!t) return TREEE_OK;
 	(void)hipSetDevice(t->device);
-	// uses from other streams: the owners' streams wait for them before the arrays can be handed out again.  (The
-	// cloud's own events are retired when its last reference goes; retiring them here too keeps a still-shared
-	// cloud's owner ordered behind this handle's users.)
-	if (t->sc) retire(t->sc->owner, &t->sc->sync);
+	// uses from other streams: the owners' streams wait for them before the arrays can be handed out again.  The sorted
+	// cloud may still be shared with an octree: its own events (and `ready`, which lets a foreign stream wait for the build
+	// only) are retired by SortedCloud::release when the LAST reference goes; here its owner is merely ordered behind this
+	// handle's users.
+	if (t->sc && t->sc.use_count() > 1) wait_users(t->sc->owner, &t->sc->sync);
 	retire(t->owner, &t->sync);
 	t->sc.reset();
 	pool_release(t->owner, t->d_bvh);

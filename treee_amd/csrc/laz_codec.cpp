@@ -970,13 +970,13 @@ void compress_chunk(const uint8_t *rec, uint64_t n, const uint16_t *types, const
 
 } // namespace
 
-extern "C" {
+namespace { // the bodies of the entry points below (which only add the exception barrier)
 
 // The chunk table behind the point data (`laz` 0.9.2 ChunkTable::read_from, laz.rs:80): the i64 at offset_to_point_data is
 // its position (-1: the file's last 8 bytes hold it); there a version u32 (0), the number of chunks u32, and the chunks'
 // byte sizes range-coded with a 32-bit integer decompressor (context 1, each predicted by the one before; with a variable
 // chunk size the point counts come first in context 0).
-int32_t treee_laz_chunk_table(const uint8_t *file, uint64_t file_len, uint64_t offset_to_point_data, uint32_t chunk_size, uint64_t total_points,
+static int32_t treee_laz_chunk_table_impl(const uint8_t *file, uint64_t file_len, uint64_t offset_to_point_data, uint32_t chunk_size, uint64_t total_points,
                               uint64_t *byte_counts_out, uint64_t *point_counts_out, uint64_t cap, uint64_t *n_chunks_out) {
 	if (!file || !n_chunks_out) return treee::set_err(TREEE_ERR_INVALID, "treee_laz_chunk_table: null argument");
 	*n_chunks_out = 0;
@@ -1019,7 +1019,7 @@ int32_t treee_laz_chunk_table(const uint8_t *file, uint64_t file_len, uint64_t o
 
 // Laz::read for a LAZ source (laz.rs:130-180): every chunk decompressed into its place in `dst` (records of
 // sum(item_sizes) bytes, chunk after chunk), one chunk per task on `threads` host threads (0 = all).
-int32_t treee_laz_decompress_chunks(const uint8_t *file, uint64_t file_len, const uint16_t *item_types, const uint16_t *item_sizes, const uint16_t *item_versions,
+static int32_t treee_laz_decompress_chunks_impl(const uint8_t *file, uint64_t file_len, const uint16_t *item_types, const uint16_t *item_sizes, const uint16_t *item_versions,
                                     uint32_t n_items, const uint64_t *chunk_starts, const uint64_t *chunk_bytes, const uint64_t *chunk_points, uint64_t n_chunks,
                                     uint32_t threads, uint8_t *dst, uint64_t dst_len) {
 	if (n_chunks == 0) return TREEE_OK;
@@ -1044,27 +1044,43 @@ int32_t treee_laz_decompress_chunks(const uint8_t *file, uint64_t file_len, cons
 	if ((uint64_t)nt > n_chunks) nt = (uint32_t)n_chunks;
 	std::atomic<uint64_t> next{0};
 	std::atomic<int64_t> failed{-1};
+	std::atomic<bool> threw{false};
 	auto work = [&]() {
 		for (;;) {
 			const uint64_t c = next.fetch_add(1);
 			if (c >= n_chunks || failed.load() >= 0) return;
-			const int32_t rc = decompress_chunk(file + chunk_starts[c], chunk_bytes[c], item_types, item_sizes, item_versions, n_items, chunk_points[c], dst + first[c] * rec);
+			int32_t rc;
+			try { // (nothing may leave a std::thread's function: an escaping exception is std::terminate)
+				rc = decompress_chunk(file + chunk_starts[c], chunk_bytes[c], item_types, item_sizes, item_versions, n_items, chunk_points[c], dst + first[c] * rec);
+			} catch (...) {
+				threw = true;
+				rc = TREEE_ERR_NOMEM;
+			}
 			if (rc != TREEE_OK) {
 				int64_t none = -1;
 				failed.compare_exchange_strong(none, (int64_t)c);
 			}
 		}
 	};
-	if (nt == 1) {
-		work();
-	} else {
-		std::vector<std::thread> pool;
-		for (uint32_t t = 0; t < nt; ++t) pool.emplace_back(work);
-		for (auto &t : pool) t.join();
-	}
-	if (failed.load() >= 0) { // decode that chunk again here for its message
-		const uint64_t c = (uint64_t)failed.load();
-		return decompress_chunk(file + chunk_starts[c], chunk_bytes[c], item_types, item_sizes, item_versions, n_items, chunk_points[c], dst + first[c] * rec);
+	try {
+		if (nt == 1) {
+			work();
+		} else {
+			std::vector<std::thread> pool;
+			try {
+				for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(work);
+			} catch (...) { // (no more threads to be had: the ones that exist and this one do the work)
+			}
+			work();
+			for (auto &t : pool) t.join();
+		}
+		if (threw) return treee::set_err(TREEE_ERR_NOMEM, "LAZ: out of memory while decompressing chunk %lld", (long long)failed.load());
+		if (failed.load() >= 0) { // decode that chunk again here for its message
+			const uint64_t c = (uint64_t)failed.load();
+			return decompress_chunk(file + chunk_starts[c], chunk_bytes[c], item_types, item_sizes, item_versions, n_items, chunk_points[c], dst + first[c] * rec);
+		}
+	} catch (const std::exception &e) {
+		return treee::set_err(TREEE_ERR_NOMEM, "LAZ: %s", e.what());
 	}
 	return TREEE_OK;
 }
@@ -1074,7 +1090,7 @@ int32_t treee_laz_decompress_chunks(const uint8_t *file, uint64_t file_len, cons
 // `chunk_size` points compressed on `threads` host threads (0 = all), the chunk table behind them.  The reference never
 // writes LAZ; this exists for fixtures and for the streamed-LAZ benchmark input.  `out` needs *out_len_out bytes: a call
 // whose `cap` is too small fails with TREEE_ERR_INVALID after setting it (random records can grow by a few per cent).
-int32_t treee_laz_encode(const uint8_t *las, uint64_t las_len, uint32_t chunk_size, uint32_t threads, uint8_t *out, uint64_t cap, uint64_t *out_len_out) {
+static int32_t treee_laz_encode_impl(const uint8_t *las, uint64_t las_len, uint32_t chunk_size, uint32_t threads, uint8_t *out, uint64_t cap, uint64_t *out_len_out) {
 	if (!las || !out_len_out) return treee::set_err(TREEE_ERR_INVALID, "treee_laz_encode: null argument");
 	*out_len_out = 0;
 	if (las_len < 375 || std::memcmp(las, "LASF", 4) != 0) return treee::set_err(TREEE_ERR_INVALID, "treee_laz_encode: not a LAS image (laz.rs:274-284)");
@@ -1104,21 +1120,31 @@ int32_t treee_laz_encode(const uint8_t *las, uint64_t las_len, uint32_t chunk_si
 		if (nt == 0) nt = 1;
 		if ((uint64_t)nt > n_chunks) nt = (uint32_t)(n_chunks ? n_chunks : 1);
 		std::atomic<uint64_t> next{0};
+		std::atomic<bool> threw{false};
 		auto work = [&]() {
-			for (;;) {
-				const uint64_t c = next.fetch_add(1);
-				if (c >= n_chunks) return;
-				const uint64_t first = c * chunk_size, cnt = std::min<uint64_t>(chunk_size, n - first);
-				compress_chunk(rec + first * rl, cnt, types, sizes, n_items, rl, chunks[c]);
+			try {
+				for (;;) {
+					const uint64_t c = next.fetch_add(1);
+					if (c >= n_chunks || threw) return;
+					const uint64_t first = c * chunk_size, cnt = std::min<uint64_t>(chunk_size, n - first);
+					compress_chunk(rec + first * rl, cnt, types, sizes, n_items, rl, chunks[c]);
+				}
+			} catch (...) {
+				threw = true;
 			}
 		};
 		if (nt == 1) {
 			work();
 		} else {
 			std::vector<std::thread> pool;
-			for (uint32_t t = 0; t < nt; ++t) pool.emplace_back(work);
+			try {
+				for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(work);
+			} catch (...) {
+			}
+			work();
 			for (auto &t : pool) t.join();
 		}
+		if (threw) return treee::set_err(TREEE_ERR_NOMEM, "treee_laz_encode: out of memory");
 	}
 	Encoder te; // chunk table: version 0, count, byte sizes (context 1, each predicted by the one before)
 	if (n_chunks) {
@@ -1177,6 +1203,37 @@ int32_t treee_laz_encode(const uint8_t *las, uint64_t las_len, uint32_t chunk_si
 	std::memcpy(p + 4, &nc32, 4);
 	if (!te.out.empty()) std::memcpy(p + 8, te.out.data(), te.out.size());
 	return TREEE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int32_t treee_laz_chunk_table(const uint8_t *file, uint64_t file_len, uint64_t offset_to_point_data, uint32_t chunk_size, uint64_t total_points,
+                              uint64_t *byte_counts_out, uint64_t *point_counts_out, uint64_t cap, uint64_t *n_chunks_out) {
+	try { // nothing unwinds across the C ABI
+		return treee_laz_chunk_table_impl(file, file_len, offset_to_point_data, chunk_size, total_points, byte_counts_out, point_counts_out, cap, n_chunks_out);
+	} catch (const std::exception &e) {
+		return treee::set_err(TREEE_ERR_NOMEM, "treee_laz_chunk_table: %s", e.what());
+	}
+}
+
+int32_t treee_laz_decompress_chunks(const uint8_t *file, uint64_t file_len, const uint16_t *item_types, const uint16_t *item_sizes, const uint16_t *item_versions,
+                                    uint32_t n_items, const uint64_t *chunk_starts, const uint64_t *chunk_bytes, const uint64_t *chunk_points, uint64_t n_chunks,
+                                    uint32_t threads, uint8_t *dst, uint64_t dst_len) {
+	try { // nothing unwinds across the C ABI
+		return treee_laz_decompress_chunks_impl(file, file_len, item_types, item_sizes, item_versions, n_items, chunk_starts, chunk_bytes, chunk_points, n_chunks, threads, dst, dst_len);
+	} catch (const std::exception &e) {
+		return treee::set_err(TREEE_ERR_NOMEM, "treee_laz_decompress_chunks: %s", e.what());
+	}
+}
+
+int32_t treee_laz_encode(const uint8_t *las, uint64_t las_len, uint32_t chunk_size, uint32_t threads, uint8_t *out, uint64_t cap, uint64_t *out_len_out) {
+	try { // nothing unwinds across the C ABI
+		return treee_laz_encode_impl(las, las_len, chunk_size, threads, out, cap, out_len_out);
+	} catch (const std::exception &e) {
+		return treee::set_err(TREEE_ERR_NOMEM, "treee_laz_encode: %s", e.what());
+	}
 }
 
 } // extern "C"

@@ -148,6 +148,10 @@ class Laz:
         if nc.value:
             _lib.check(_lib.lib().treee_laz_chunk_table(ptr(buf), len(buf), h.offset_to_point_data, v["chunk_size"], total, ptr(nb), ptr(npnt), nc.value, C.byref(nc)))
         self.chunks, self._chunk_bytes = [], []
+        # Where the reference stands: laz.rs:76-80 seeks to header_size, scans the VLRs and calls ChunkTable::read_from AT THE
+        # POSITION THE SCAN ENDED, i.e. header_size + the VLRs' bytes; the chunks follow 8 bytes later.  A well-formed file has
+        # offset_to_point_data there.  DEVIATION (documented): this reader takes the header's offset_to_point_data --
+        # a file with padding between its last VLR and the point data is read here and fails in the reference.
         start = h.offset_to_point_data + 8  # the reader's position after ChunkTable::read_from
         for b, c in zip(nb.tolist(), npnt.tolist()):
             self.chunks.append((start, c))

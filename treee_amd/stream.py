@@ -53,8 +53,11 @@ class LazTile:
         counts = np.asarray([c for _, c in src.chunks], dtype=np.uint64)
         nbytes = np.asarray(src._chunk_bytes, dtype=np.uint64)
         buf = np.frombuffer(src.data, np.uint8)
+        if out.numel() * out.element_size() < self.n * self.stride:
+            raise ValueError(f"decompress_into: the buffer holds {out.numel() * out.element_size()} bytes, the tile needs {self.n * self.stride}")
+        # dst_len = the buffer's real capacity: the library refuses records that would not fit (no Python assert to strip)
         _lib.check(_lib.lib().treee_laz_decompress_chunks(ptr(buf), len(buf), ptr(types), ptr(sizes), ptr(versions), len(items), ptr(starts), ptr(nbytes),
-                                                          ptr(counts), len(src.chunks), threads, ptr(out), self.n * self.stride))
+                                                          ptr(counts), len(src.chunks), threads, ptr(out), out.numel() * out.element_size()))
         self.records = out
 
 
@@ -154,7 +157,8 @@ class TileStream:
                 self.pinned = [torch.empty((self.max_points * self.max_stride,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
                 self.pinned_read = [torch.cuda.Event() for _ in range(2)]  # the H2D copy that last read each staging buffer
                 self.pool = ThreadPoolExecutor(max_workers=1)
-            assert tile.n <= self.max_points and tile.stride <= self.max_stride
+            if tile.n > self.max_points or tile.stride > self.max_stride:
+                raise ValueError(f"tile of {tile.n} x {tile.stride} B exceeds the stream's {self.max_points} x {self.max_stride} B")
             slot = k & 1
             k += 1
             self.pinned_read[slot].synchronize()  # (two LAZ tiles ago)
@@ -180,7 +184,8 @@ class TileStream:
     def _upload(self, tile, slot, first):
         torch = self.torch
         nbytes = tile.n * tile.stride
-        assert tile.n <= self.max_points and tile.stride <= self.max_stride
+        if tile.n > self.max_points or tile.stride > self.max_stride:
+            raise ValueError(f"tile of {tile.n} x {tile.stride} B exceeds the stream's {self.max_points} x {self.max_stride} B")
         with torch.cuda.stream(self.copy):
             if not first:
                 self.copy.wait_event(self.consumed[slot])
