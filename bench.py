@@ -339,6 +339,9 @@ def main():
             out["segmentation_host"] = segmentation_stage()
             out["eye_dome"] = eye_dome_stage(depth, ctx)
             out["out_of_core"] = out_of_core_stage(dev, n, proj)
+            free_state()
+            torch.cuda.empty_cache()
+            out["config3_150M_one_gpu"] = whole_150m_stage()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -346,6 +349,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def whole_150m_stage():
+    """BASELINE.json configs[3]'s cloud -- 150 M points, 632 m plot, the 15 M configuration's density -- as ONE GPU runs it (the N = 1 point
+    of the strong-scaling curve `--total-points 150000000 --gpus N` draws): the same step in a child process of this one (its own JSON
+    line, reduced here).  Beside the main line, not part of `value`."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--points", "150000000", "--plot", "632", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"workload": d["config"]["workload"], "Mpoints_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "stages_ms": {k: v["ms"] for k, v in d["stages"].items()}, "knn_roofline_frac": d["roofline"]["frac"]}
+    except Exception as e:  # (a side measurement must not take the main line down)
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def measured_copy_gbps(dev):
