@@ -20,6 +20,7 @@
 // throws.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <limits>
@@ -142,6 +143,18 @@ inline std::vector<float> curvature_segments(const std::vector<Point3> &data, co
 		check(treee_curvature_segments(data[0].data(), segment.data(), data.size(), n_segments, neighbors_count, neighbors_max_distance, curve.data()));
 	return curve;
 }
+// ... and over several GPUs of this process, whole segments per device, nothing exchanged -- the way Calculations::new
+// spreads segments over rayon workers (calculations.rs:97-118); bit for bit the single-device result
+inline std::vector<float> curvature_segments(const std::vector<int32_t> &devices, const std::vector<Point3> &data, const std::vector<uint32_t> &segment,
+                                             uint32_t n_segments, uint32_t neighbors_count = NEIGHBORS_COUNT,
+                                             float neighbors_max_distance = NEIGHBORS_MAX_DISTANCE) {
+	if (segment.size() != data.size()) throw Error(TREEE_ERR_INVALID, "segment.len() != points.len()");
+	std::vector<float> curve(data.size());
+	if (!data.empty())
+		check(treee_curvature_segments_multi(devices.data(), (uint32_t)devices.size(), data[0].data(), segment.data(), data.size(), n_segments, neighbors_count,
+		                                     neighbors_max_distance, curve.data()));
+	return curve;
+}
 // ---- the Segmenting phase (segmenting.rs:110-235): the `segment: Vec<u32>` of Event::PointCloud (program.rs:18-22) ----
 constexpr float DEFAULT_MAX_DISTANCE = 0.75f; // segmenting.rs:16
 constexpr uint32_t DELETED_INDEX = 0;         // interactive/mod.rs:19
@@ -256,5 +269,66 @@ inline std::vector<int64_t> slice_keys(const std::vector<Point3> &points) {
 	if (!points.empty()) check(treee_slice_keys(points[0].data(), points.size(), keys.data()));
 	return keys;
 }
+
+// ---- several processes, one GPU each (no reference counterpart: the reference is one process) ------------------------
+// The plan of the sharded octree (treee_hip.h, "the sharded octree"): pure host arithmetic, the same on every rank.
+class ShardPlan {
+public:
+	// cell_counts[world][8^top_level]: points of every rank's input per level-top_level Morton cell of the common cube
+	ShardPlan(const std::vector<uint32_t> &cell_counts, int32_t world, uint32_t top_level, uint32_t leaf_cap = 256, uint32_t lod_cap = 256) {
+		if (cell_counts.size() != (size_t)world << (3u * top_level)) throw Error(TREEE_ERR_INVALID, "cell_counts is not world x 8^top_level");
+		check(treee_shard_plan_create(cell_counts.data(), world, top_level, leaf_cap, lod_cap, &h_));
+		check(treee_shard_plan_info_get(h_, &info));
+	}
+	ShardPlan(const ShardPlan &) = delete;
+	ShardPlan &operator=(const ShardPlan &) = delete;
+	~ShardPlan() { treee_shard_plan_free(h_); }
+	treee_shard_plan_info info{};
+	treee_shard_plan_rank rank(int32_t r) const {
+		treee_shard_plan_rank out{};
+		check(treee_shard_plan_rank_get(h_, r, &out));
+		return out;
+	}
+	std::vector<treee_octree_node> top_nodes() const {
+		std::vector<treee_octree_node> v(info.n_top_nodes);
+		check(treee_shard_plan_top_nodes(h_, v.data()));
+		return v;
+	}
+	std::vector<treee_octree_node> level_nodes(int32_t r) const {
+		std::vector<treee_octree_node> v(rank(r).level_node_count);
+		check(treee_shard_plan_level_nodes(h_, r, v.data()));
+		return v;
+	}
+
+private:
+	treee_shard_plan *h_ = nullptr;
+};
+
+// A communicator over transport functions the host supplies (MPI, sockets ...); `loopback()` is the one-rank case.
+class Comm {
+public:
+	Comm(const treee_comm_host_ops &ops, int32_t rank, int32_t world) { check(treee_comm_create_host(&ops, rank, world, &h_)); }
+	static Comm loopback() {
+		treee_comm_host_ops ops{};
+		ops.all_gather = [](void *, const void *send, void *recv, uint64_t bytes) -> int32_t {
+			std::copy((const char *)send, (const char *)send + bytes, (char *)recv);
+			return 0;
+		};
+		ops.all_to_all_v = [](void *, const void *send, const uint64_t *so, const uint64_t *sb, void *recv, const uint64_t *ro, const uint64_t *) -> int32_t {
+			std::copy((const char *)send + so[0], (const char *)send + so[0] + sb[0], (char *)recv + ro[0]);
+			return 0;
+		};
+		ops.all_reduce_min_u64 = [](void *, uint64_t *, uint64_t) -> int32_t { return 0; };
+		return Comm(ops, 0, 1);
+	}
+	Comm(const Comm &) = delete;
+	Comm &operator=(const Comm &) = delete;
+	Comm(Comm &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+	~Comm() { treee_comm_destroy(h_); }
+	treee_comm *handle() const { return h_; }
+
+private:
+	treee_comm *h_ = nullptr;
+};
 
 } // namespace treee

@@ -111,15 +111,15 @@ int main() {
 		const std::vector<float> curve = treee::curvature(points);
 		std::vector<float> want(n);
 		orc_curvature(points[0].data(), n, 31, treee::NEIGHBORS_MAX_DISTANCE, want.data(), 8);
-		size_t close = 0;
+		size_t same = 0;
 		for (size_t i = 0; i < n; ++i) {
 			CHECK(std::isnan(curve[i]) == std::isnan(want[i]));
 			if (!std::isnan(want[i])) {
-				CHECK(std::fabs(curve[i] - want[i]) < 1e-4f); // tie order and acos/cos differ
-				close += std::fabs(curve[i] - want[i]) < 1e-5f;
+				CHECK(std::fabs(curve[i] - want[i]) < 1e-4f); // rows with a distance tie may hold another member or sum in another order
+				same += std::memcmp(&curve[i], &want[i], 4) == 0; // everywhere else: bit for bit (acos / cos: include/treee_f32_trig.h on both sides)
 			}
 		}
-		CHECK(close > n * 0.999);
+		CHECK(same > n * 0.995);
 		for (float v : {-1.0f, 0.0f, 1e-10f, 0.25f, 0.9999999f, 1.0f, 7.0f, NAN}) CHECK(treee::map_to_u32(v) == orc_map_to_u32(v));
 		// every segment at once == segment by segment
 		std::vector<uint32_t> segment(n);
@@ -138,6 +138,44 @@ int main() {
 			for (size_t i = 0; i < part.size(); ++i)
 				if (!std::isnan(w[i])) CHECK(std::fabs(both[where[i]] - w[i]) < 1e-4f);
 		}
+	}
+	// ---- whole segments over a device list (calculations.rs:97-118): the single-device result, bit for bit -------------
+	{
+		std::vector<uint32_t> segment(n);
+		for (size_t i = 0; i < n; ++i) segment[i] = (uint32_t)(points[i][0] / 4.0f) % 7u;
+		const std::vector<float> one = treee::curvature_segments(points, segment, 7);
+		for (const std::vector<int32_t> &devices : {std::vector<int32_t>{0}, std::vector<int32_t>{0, 0}}) {
+			const std::vector<float> many = treee::curvature_segments(devices, points, segment, 7);
+			CHECK(many.size() == one.size() && std::memcmp(many.data(), one.data(), one.size() * 4) == 0);
+		}
+	}
+	// ---- the sharded octree's host arithmetic and the loopback communicator (treee_hip.h, "many GPUs") ------------------
+	{
+		const uint32_t L = 2, ncell = 64;
+		std::vector<uint32_t> counts(2 * ncell, 0);
+		for (uint32_t c = 0; c < ncell; ++c) {
+			counts[c] = c < 40 ? 500 + c : 0;          // rank 0's input: the low cells
+			counts[ncell + c] = c >= 24 ? 300 + c : 0; // rank 1's: the high ones, overlapping in 24 .. 39
+		}
+		treee::ShardPlan plan(counts, 2, L, 64, 16);
+		const treee_shard_plan_rank r0 = plan.rank(0), r1 = plan.rank(1);
+		uint64_t total = 0;
+		for (uint32_t v : counts) total += v;
+		CHECK(plan.info.n_total == total && r0.count + r1.count == total && r0.first == 0 && r1.first == r0.count);
+		CHECK(r0.cell_begin == 0 && r0.cell_end == r1.cell_begin && r1.cell_end == ncell && r1.index_base > 0);
+		const std::vector<treee_octree_node> top = plan.top_nodes();
+		CHECK(!top.empty() && top[0].count == total && top[0].level == 0 && top[0].first_child == 1);
+		size_t level_nodes = 0;
+		for (const treee_octree_node &nd : top) CHECK(nd.level < L);
+		for (int r = 0; r < 2; ++r)
+			for (const treee_octree_node &nd : plan.level_nodes(r)) {
+				CHECK(nd.level == L && nd.count > 0 && nd.key_prefix >= plan.rank(r).cell_begin && nd.key_prefix < plan.rank(r).cell_end);
+				++level_nodes;
+			}
+		CHECK(level_nodes == plan.info.n_level_nodes);
+		treee::Comm comm = treee::Comm::loopback();
+		int32_t rank = -1, world = -1, rccl = -1;
+		CHECK(treee_comm_info(comm.handle(), &rank, &world, &rccl) == TREEE_OK && rank == 0 && world == 1 && rccl == 0);
 	}
 	// ---- SegmentData::new + SegmentInformation::new / update for all segments (calculations.rs:133-327) ---------
 	{
