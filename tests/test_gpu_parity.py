@@ -1377,11 +1377,16 @@ def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
         pts = whole[cut[rank] : cut[rank + 1]]
     elif layout == "one_empty":
         pts = whole if rank == 0 else whole[:0]
+    elif layout == "one_cell":  # a given cube far larger than the cloud: every point in ONE shard-level cell, a rank owns nothing
+        pts = whole[rank::world][:30_000] * np.float32(0.01) + np.float32(5.0)
+    elif layout == "full_size":  # configs[1]'s 15 M points as two tiles
+        pts, _ = synth.forest_cloud(7_500_000, plot=141.4, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, 141.4))
     else:
         pts, _ = synth.forest_cloud(200_000, plot=30.0, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, 30.0))
     pts = np.ascontiguousarray(pts, np.float32)
     comm = D.Comm.host()
-    so = T.ShardedOctree(torch.from_numpy(pts).cuda(), comm, leaf_cap=64, lod_cap=32, top_level=top_level)
+    cube = dict(corner=np.zeros(3, np.float32), size=4096.0) if layout == "one_cell" else {}
+    so = T.ShardedOctree(torch.from_numpy(pts).cuda(), comm, leaf_cap=64, lod_cap=32, top_level=top_level, **cube)
     # the frame of the rank's own points, min-reduced through the same communicator (treee_frame_reduce_min_dev)
     w, h = 160, 90
     view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 70.0))
@@ -1401,7 +1406,8 @@ def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,layout,top_level", [(2, "tiles", 0), (2, "interleaved", 4), (3, "skewed", 2), (3, "interleaved", 5), (2, "one_empty", 3)])
+@pytest.mark.parametrize("world,layout,top_level", [(2, "tiles", 0), (2, "interleaved", 4), (3, "skewed", 2), (3, "interleaved", 5), (2, "one_empty", 3),
+                                                    (3, "one_cell", 2), (2, "full_size", 0)])
 def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_path, world, layout, top_level):
     """SURVEY 8 E / BASELINE configs[3]: the ranks (sharing this GPU, host transport over gloo) build
     their pieces of ONE octree -- common cube, Morton-prefix ownership, one all-to-all, replicated top, global numbering --
@@ -1417,12 +1423,16 @@ def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_
     mp.spawn(_sharded_octree_worker, args=(world, port, str(tmp_path), layout, top_level), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"so{r}.pt"), weights_only=False) for r in range(world)]
     whole = np.concatenate([r["pts"] for r in res])
-    corner, size = cube_of(whole)
+    corner, size = (np.zeros(3, np.float32), 4096.0) if layout == "one_cell" else cube_of(whole)
     for r in res:
         assert np.array_equal(r["corner"], corner) and r["size"] == size
     _assert_assembles_to(T, oracle, [r["piece"] for r in res], whole, corner, size, 64, 32)
     counts = [r["piece"]["count"] for r in res]
-    assert sum(counts) == len(whole) and max(counts) - min(counts) <= 0.25 * len(whole) / world
+    assert sum(counts) == len(whole)
+    if layout == "one_cell":
+        assert sorted(counts) == [0] * (world - 1) + [len(whole)]  # one cell cannot be split: its owner holds everything
+    else:
+        assert max(counts) - min(counts) <= 0.25 * len(whole) / world
     # the reduced frame = the frame one GPU draws of the whole cloud
     w, h = 160, 90
     view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 70.0))
