@@ -71,29 +71,6 @@ __device__ __forceinline__ bool footprint(const SplatParams &P, float x, float y
 }
 
 __device__ __forceinline__ float row_v(const Foot &f, int py) { return (((float)py + 0.5f) - f.sy) / f.ry; }
-// The coverage rule of point_cloud.wgsl:74-76 is u * u + v * v < 1 with u, v two IEEE divisions per pixel -- a dozen instructions
-// each, and a splat's pixel box holds several pixels for every one its disc covers.  The decision is taken from the same
-// expression with the divisions replaced by a multiplication with v_rcp_f32's reciprocal (relative error < 2e-7 per term, < 2e-6
-// on the sum near 1) whenever that sum is farther than 1e-5 from 1; in the band around 1 -- and for anything non-finite -- the
-// exact expression decides.  Same pixels as the rule itself, hence as oracle/splat_oracle.cpp.
-struct FastCover {
-	float inv_rx, inv_ry;
-	__device__ __forceinline__ explicit FastCover(const Foot &f) : inv_rx(__builtin_amdgcn_rcpf(f.rx)), inv_ry(__builtin_amdgcn_rcpf(f.ry)) {}
-	__device__ __forceinline__ float row(const Foot &f, int py) const { // ~ v * v of the row
-		const float va = (((float)py + 0.5f) - f.sy) * inv_ry;
-		return va * va;
-	}
-	__device__ __forceinline__ bool covers(const Foot &f, int px, int py, float va2) const {
-		const float ua = (((float)px + 0.5f) - f.sx) * inv_rx;
-		const float ta = ua * ua + va2;
-		if (ta < 0.99999f) return true;
-		if (ta > 1.00001f) return false;
-		const float u = (((float)px + 0.5f) - f.sx) / f.rx, v = row_v(f, py); // the band around the rim, NaN, inf: the rule itself
-		return u * u + v * v < 1.0f;
-	}
-};
-// (a row none of whose pixels can pass: v * v alone is beyond the band)
-__device__ __forceinline__ bool row_out(float va2) { return va2 > 1.00001f; }
 // v = row_v(f, py): the same for a whole row, so the caller computes it (and its IEEE divide) once per row
 __device__ __forceinline__ void plot(unsigned long long *packed, uint32_t w, const Foot &f, int px, int py, float v, unsigned long long mine) {
 	const float u = (((float)px + 0.5f) - f.sx) / f.rx;
@@ -141,15 +118,10 @@ __global__ __launch_bounds__(256) void k_splat_points(const void *__restrict__ p
 		return;
 	}
 	const unsigned long long mine = ((unsigned long long)__float_as_uint(f.depth) << 32) | (unsigned long long)(P.index_base + orig);
-	const FastCover fc(f);
 	for (int py = f.y0; py < f.y1; ++py) {
-		const float va2 = fc.row(f, py);
-		if (row_out(va2)) continue; // (u * u >= 0: no pixel of this row can pass)
-		for (int px = f.x0; px < f.x1; ++px) {
-			if (!fc.covers(f, px, py, va2)) continue;
-			unsigned long long *q = packed + (size_t)py * P.w + px;
-			if (mine < *q) atomicMin(q, mine); // stale read is conservative: values only decrease
-		}
+		const float v = row_v(f, py);
+		if (!(v * v < 1.0f)) continue; // (u * u >= 0: no pixel of this row can pass; NaN rows never pass either)
+		for (int px = f.x0; px < f.x1; ++px) plot(packed, P.w, f, px, py, v, mine);
 	}
 }
 
@@ -217,14 +189,18 @@ __global__ __launch_bounds__(256) void k_splat_tile(const float4 *__restrict__ r
 #pragma unroll
 	for (int k = 0; k < TILE_PPT; ++k) {
 		if (!draw[k]) continue;
-		const FastCover fc(f[k]);
 		for (int py = f[k].y0; py < f[k].y1; ++py) {
-			const float va2 = fc.row(f[k], py);
-			if (row_out(va2)) continue;
+			const float v = row_v(f[k], py);
+			if (!(v * v < 1.0f)) continue;
 			for (int px = f[k].x0; px < f[k].x1; ++px) {
-				if (!fc.covers(f[k], px, py, va2)) continue; // point_cloud.wgsl:74-76
-				unsigned long long *q = tiled ? &s_tile[(py - by0) * bw + (px - bx0)] : packed + (size_t)py * P.w + px;
-				if (mine[k] < *q) atomicMin(q, mine[k]); // (LDS tile or the frame itself; stale read is conservative: values only decrease)
+				if (!tiled) {
+					plot(packed, P.w, f[k], px, py, v, mine[k]);
+					continue;
+				}
+				const float u = (((float)px + 0.5f) - f[k].sx) / f[k].rx;
+				if (!(u * u + v * v < 1.0f)) continue; // point_cloud.wgsl:74-76
+				unsigned long long *q = &s_tile[(py - by0) * bw + (px - bx0)];
+				if (mine[k] < *q) atomicMin(q, mine[k]);
 			}
 		}
 	}
