@@ -1379,6 +1379,19 @@ def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
         pts = whole if rank == 0 else whole[:0]
     elif layout == "one_cell":  # a given cube far larger than the cloud: every point in ONE shard-level cell, a rank owns nothing
         pts = whole[rank::world][:30_000] * np.float32(0.01) + np.float32(5.0)
+    elif layout.startswith("fuzz"):  # ragged random pieces: empty and tiny ranks, duplicates, a dense blob, an outlier
+        rng = np.random.default_rng(int(layout[4:]) * 100 + 7)
+        sizes = rng.choice([0, 1, 5, 63, 4097, 60_000], size=world)
+        parts = []
+        for r in range(world):
+            g = np.random.default_rng(int(layout[4:]) * 1000 + r)
+            p = (np.round(g.random((int(sizes[r]), 3)) * np.array([80, 20, 80]) * 1000) / 1000).astype(np.float32)
+            if len(p) > 100:
+                p[: len(p) // 4] = p[0]  # duplicates: one deep cell
+                p[len(p) // 4 : len(p) // 2] = p[len(p) // 4 : len(p) // 2] * np.float32(0.01) + np.float32(40.0)  # a dense blob
+                p[-1] = np.array([500.0, -300.0, 900.0], np.float32)  # an outlier stretches the cube
+            parts.append(p)
+        pts = parts[rank]
     elif layout == "full_size":  # configs[1]'s 15 M points as two tiles
         pts, _ = synth.forest_cloud(7_500_000, plot=141.4, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, 141.4))
     else:
@@ -1407,7 +1420,7 @@ def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
 
 
 @pytest.mark.parametrize("world,layout,top_level", [(2, "tiles", 0), (2, "interleaved", 4), (3, "skewed", 2), (3, "interleaved", 5), (2, "one_empty", 3),
-                                                    (3, "one_cell", 2), (2, "full_size", 0)])
+                                                    (3, "one_cell", 2), (2, "full_size", 0), (4, "fuzz1", 1), (3, "fuzz2", 3), (4, "fuzz3", 6), (2, "fuzz4", 4)])
 def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_path, world, layout, top_level):
     """SURVEY 8 E / BASELINE configs[3]: the ranks (sharing this GPU, host transport over gloo) build
     their pieces of ONE octree -- common cube, Morton-prefix ownership, one all-to-all, replicated top, global numbering --
@@ -1431,7 +1444,7 @@ def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_
     assert sum(counts) == len(whole)
     if layout == "one_cell":
         assert sorted(counts) == [0] * (world - 1) + [len(whole)]  # one cell cannot be split: its owner holds everything
-    else:
+    elif not layout.startswith("fuzz"):  # (a fuzz cloud's duplicates sit in one cell: balance is not promised there)
         assert max(counts) - min(counts) <= 0.25 * len(whole) / world
     # the reduced frame = the frame one GPU draws of the whole cloud
     w, h = 160, 90
