@@ -1422,7 +1422,8 @@ def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
 @pytest.mark.parametrize("world,layout,top_level", [(2, "tiles", 0), (2, "interleaved", 4), (3, "skewed", 2), (3, "interleaved", 5), (2, "one_empty", 3),
                                                     (3, "one_cell", 2), (2, "full_size", 0), (4, "fuzz1", 1), (3, "fuzz2", 3), (4, "fuzz3", 6), (2, "fuzz4", 4)])
 def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_path, world, layout, top_level):
-    """SURVEY 8 E / BASELINE configs[3]: the ranks (sharing this GPU, host transport over gloo) build
+    """(world <= 4: the GPU box allows six processes on its card and this test process is one of them.)
+    SURVEY 8 E / BASELINE configs[3]: the ranks (sharing this GPU, host transport over gloo) build
     their pieces of ONE octree -- common cube, Morton-prefix ownership, one all-to-all, replicated top, global numbering --
     and the pieces are, bit for bit, the octree one GPU builds of the concatenated cloud."""
     import socket
