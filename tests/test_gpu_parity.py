@@ -187,6 +187,34 @@ def test_knn_radius_and_empty_vs_reference(T, oracle):
             assert tree.empty(q, r) == ref.empty(q, r)
 
 
+def test_knn_structure_from_an_octree_orders_cells_like_the_point_sort(T):
+    """the kNN structure over an octree's Morton-sorted cloud gets its Hilbert order by sorting the occupied 2^-10 cells and moving
+    their points as they stand (knn.hip, hilbert_order_by_cells) when a cell holds two points or more on average; a structure built from
+    the raw points sorts the points.  Both orders are (Hilbert index of the cell, original index): every neighbour list -- distances AND
+    indices, the tie rule included -- must come out identical.  Forest patch (cells path), duplicates, and a uniform cloud (one point per
+    cell: the point sort behind the octree too)."""
+    import torch
+
+    from treee_amd import synth
+
+    forest, _ = synth.forest_cloud(400_000, plot=30.0)
+    dup = np.concatenate([forest[:50_000], forest[:50_000], forest[:10_000]])
+    uniform = quantised_cloud(100_000, 17, extent=(2000, 2000, 2000))
+    for name, pts in (("forest", forest), ("duplicates", dup), ("uniform", uniform)):
+        d_pts = torch.from_numpy(pts).cuda()
+        oc = T.Octree(d_pts)
+        a = T.KDTree.from_octree(oc)
+        b = T.KDTree.new(d_pts)
+        for k in (31, 8):
+            da, ia, ca = a.self_neighbors_dev(k)
+            db, ib, cb = b.self_neighbors_dev(k)
+            assert torch.equal(da.view(torch.int32), db.view(torch.int32)) and torch.equal(ia, ib) and torch.equal(ca, cb), (name, k)
+        assert torch.equal(a.curvature_dev(31).view(torch.int32), b.curvature_dev(31).view(torch.int32)), name
+        a.close()
+        b.close()
+        oc.close()
+
+
 # ---------------------------------------------------------------- A5 curvature
 def same_f32(a, b):
     """bit-identical f32 arrays; NaN matches NaN (0/0 has the sign bit set on x86 and clear on gfx950)"""

@@ -1322,6 +1322,91 @@ __global__ __launch_bounds__(256) void k_gather_rec(const float4 *__restrict__ s
 	perm[i] = __float_as_uint(r.w);
 }
 
+// ---- Hilbert order of a Morton-sorted cloud by ordering CELLS instead of points ------------------------------------------------
+// The points of one 2^-10 cell share their Morton key and their Hilbert index, are contiguous in the Morton order and keep
+// their relative order (both sorts are stable by original index).  So the Hilbert order of the cloud is: the occupied cells
+// in the order of their Hilbert index, each with its points as they stand.  A forest scan puts ~10 points into an occupied
+// cell, so sorting the K cells is a tenth of sorting the n points; the rest is streaming: head flags + scan (the cell of
+// every point), one key per cell, the cells' sizes scanned in Hilbert order, and one pass that moves every record to
+// cell destination + position inside the cell -- which also replaces the record gather (runs of a cell's records are
+// WRITTEN contiguously instead of single records being read from all over the cloud).  Same result as sort_pairs_dev on the
+// points' Hilbert indices, bit for bit; taken when K <= n / 2 (a uniform cloud has K ~ n and keeps the point sort).
+__global__ __launch_bounds__(256) void k_cell_heads(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ flag) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_cell_emit(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ cid_ex,
+                                                    uint32_t n, uint32_t n_cells, uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cell_hkey) {
+	__shared__ uint16_t s_lut[24 * 8];
+	if (threadIdx.x < 24 * 8) {
+		constexpr uint16_t LUT[24 * 8] = {TREEE_HILBERT_LUT_INIT};
+		s_lut[threadIdx.x] = LUT[threadIdx.x];
+	}
+	__syncthreads();
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i == 0) cell_start[n_cells] = n;
+	if (i >= n || !flag[i]) return;
+	const uint32_t c = cid_ex[i];
+	cell_start[c] = i;
+	cell_hkey[c] = hilbert_of_morton_lut(keys[i], s_lut);
+}
+__global__ __launch_bounds__(256) void k_cell_len(const uint32_t *__restrict__ order, const uint32_t *__restrict__ cell_start, uint32_t n_cells,
+                                                   uint32_t *__restrict__ len_sorted) {
+	const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j >= n_cells) return;
+	const uint32_t c = order[j];
+	len_sorted[j] = cell_start[c + 1u] - cell_start[c];
+}
+__global__ __launch_bounds__(256) void k_cell_dest(const uint32_t *__restrict__ order, const uint32_t *__restrict__ dest_sorted, uint32_t n_cells,
+                                                    uint32_t *__restrict__ cell_dest) {
+	const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+	if (j < n_cells) cell_dest[order[j]] = dest_sorted[j];
+}
+// every record to its cell's destination + its position inside the cell
+__global__ __launch_bounds__(256) void k_cell_expand(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ cid_ex,
+                                                      const uint32_t *__restrict__ cell_start, const uint32_t *__restrict__ cell_dest,
+                                                      const uint32_t *__restrict__ cell_hkey, const float4 *__restrict__ rec, uint32_t n,
+                                                      uint32_t *__restrict__ out_keys, uint32_t *__restrict__ out_perm, float4 *__restrict__ out_rec) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t c = cid_ex[i] + flag[i] - 1u;
+	const uint32_t d = cell_dest[c] + (i - cell_start[c]);
+	const float4 r = rec[i];
+	out_keys[d] = cell_hkey[c];
+	out_perm[d] = __float_as_uint(r.w);
+	out_rec[d] = r;
+}
+
+int32_t hilbert_order_by_cells(treee_ctx *ctx, const SortedCloud *sc, uint32_t n_cells, SortedCloud *fine) {
+	const uint32_t n = (uint32_t)sc->n;
+	hipStream_t st = ctx->stream;
+	uint32_t *d_flag = nullptr, *d_cid = nullptr, *d_start = nullptr, *d_hkey = nullptr, *d_hsorted = nullptr, *d_order = nullptr, *d_len = nullptr,
+	         *d_dsorted = nullptr, *d_dest = nullptr;
+	TREEE_TRY(ctx->alloc_t(n, &d_flag));
+	TREEE_TRY(ctx->alloc_t(n, &d_cid));
+	TREEE_TRY(ctx->alloc_t((size_t)n_cells + 1, &d_start));
+	TREEE_TRY(ctx->alloc_t(n_cells, &d_hkey));
+	TREEE_TRY(ctx->alloc_t(n_cells, &d_hsorted));
+	TREEE_TRY(ctx->alloc_t(n_cells, &d_order));
+	TREEE_TRY(ctx->alloc_t(n_cells, &d_len));
+	TREEE_TRY(ctx->alloc_t(n_cells, &d_dsorted));
+	TREEE_TRY(ctx->alloc_t(n_cells, &d_dest));
+	hipLaunchKernelGGL(k_cell_heads, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, n, d_flag);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_flag, d_cid, n, nullptr));
+	hipLaunchKernelGGL(k_cell_emit, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, d_flag, d_cid, n, n_cells, d_start, d_hkey);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(sort_pairs_dev(ctx, d_hkey, nullptr, n_cells, 30, d_hsorted, d_order)); // (distinct keys: no ties to keep stable)
+	hipLaunchKernelGGL(k_cell_len, dim3(div_up(n_cells, 256)), dim3(256), 0, st, d_order, d_start, n_cells, d_len);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_len, d_dsorted, n_cells, nullptr));
+	hipLaunchKernelGGL(k_cell_dest, dim3(div_up(n_cells, 256)), dim3(256), 0, st, d_order, d_dsorted, n_cells, d_dest);
+	hipLaunchKernelGGL(k_cell_expand, dim3(div_up(n, 256)), dim3(256), 0, st, d_flag, d_cid, d_start, d_dest, d_hkey, sc->d_sorted, n, fine->d_keys,
+	                   fine->d_perm, fine->d_sorted);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
 // The kNN structure's own order.  The shared sort is by Morton key (it is also the octree's); the kNN structure re-sorts a
 // private copy of the cloud by the HILBERT index of the same 10-bit cells: a bucket of 64 consecutive points is then one
 // contiguous blob instead of, every so often, two pieces on either side of a jump of the Z curve, and its queries share
@@ -1364,6 +1449,12 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_keys));
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_perm));
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_sorted));
+	static const bool no_cells = getenv("TREEE_KNN_NO_CELLSORT") != nullptr; // A/B and test hook: always sort the points
+	if (!flag && !morton_order && !sc->hilbert && !no_cells && sc->n_cells > 0 && (uint64_t)sc->n_cells * 2u <= n) {
+		TREEE_TRY(hilbert_order_by_cells(ctx, sc.get(), (uint32_t)sc->n_cells, fine.get()));
+		*out = fine;
+		return TREEE_OK;
+	}
 	uint32_t *d_lo = nullptr, *d_lo_s = nullptr, *d_pos1 = nullptr, *d_hi = nullptr, *d_pos2 = nullptr;
 	TREEE_TRY(ctx->alloc_t(n, &d_hi));
 	TREEE_TRY(ctx->alloc_t(n, &d_pos2));

@@ -502,6 +502,20 @@ int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, ui
 	return TREEE_OK;
 }
 
+__global__ __launch_bounds__(256) void k_distinct(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ count) {
+	uint32_t c = 0;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+	if (lane_id() == 0 && c) atomicAdd(count, c);
+}
+int32_t distinct_keys_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t *d_count) {
+	TREEE_HIP(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+	if (n) hipLaunchKernelGGL(k_distinct, dim3(n < 256 * 2048 ? div_up(n, 256) : 2048), dim3(256), 0, ctx->stream, d_keys, (uint32_t)n, d_count);
+	TREEE_LAUNCH_CHECK();
+	return TREEE_OK;
+}
+
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner, float size, SortedCloud *sc, bool fork_after_sort,
                            bool hilbert_order) {
 	sc->n = n;

@@ -39,17 +39,6 @@ struct P2 {
 };
 inline P2 operator-(P2 a, P2 b) { return {a.x - b.x, a.y - b.y}; }
 
-// segmenting.rs:347-353 and its copies in distance / contains: signed distance of `point` to the edge a -> b along the
-// outward unit normal normalize((dir.y, -dir.x)) (nalgebra: v / sqrt(x*x + y*y), dot = x*x' + y*y'; no FMA)
-inline float edge_dist(P2 a, P2 b, P2 point) {
-	const float dx = b.x - a.x, dy = b.y - a.y;
-	const float ox = dy, oy = -dx;
-	const float norm = std::sqrt(ox * ox + oy * oy);
-	const float nx = ox / norm, ny = oy / norm;
-	const float fx = point.x - a.x, fy = point.y - a.y;
-	return nx * fx + ny * fy;
-}
-
 // segmenting.rs:526-545
 inline void centroid(const std::vector<P2> &points, P2 *center_out, float *area_out) {
 	float cx = 0.0f, cy = 0.0f, area = 0.0f;
