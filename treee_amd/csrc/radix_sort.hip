@@ -502,16 +502,33 @@ int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, ui
 	return TREEE_OK;
 }
 
-__global__ __launch_bounds__(256) void k_distinct(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ count) {
+// (one partial per workgroup, summed by the last-but-one step on 256 threads: thousands of atomics on ONE address are
+// memory-side operations that run one after the other -- 8 192 of them cost 0.2 ms, more than reading the 60 MB of keys)
+constexpr uint32_t DISTINCT_BLOCKS = 256;
+__global__ __launch_bounds__(256) void k_distinct(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ partial) {
+	__shared__ uint32_t s_w[4];
 	uint32_t c = 0;
 	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-	if (lane_id() == 0 && c) atomicAdd(count, c);
+	if (lane_id() == 0) s_w[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(256) void k_distinct_sum(const uint32_t *__restrict__ partial, uint32_t *__restrict__ count) {
+	__shared__ uint32_t s_w[4];
+	uint32_t c = partial[threadIdx.x];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+	if (lane_id() == 0) s_w[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) *count = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 int32_t distinct_keys_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t *d_count) {
-	TREEE_HIP(hipMemsetAsync(d_count, 0, 4, ctx->stream));
-	if (n) hipLaunchKernelGGL(k_distinct, dim3(n < 256 * 2048 ? div_up(n, 256) : 2048), dim3(256), 0, ctx->stream, d_keys, (uint32_t)n, d_count);
+	uint32_t *d_partial = nullptr;
+	TREEE_TRY(ctx->alloc_t(DISTINCT_BLOCKS, &d_partial));
+	hipLaunchKernelGGL(k_distinct, dim3(DISTINCT_BLOCKS), dim3(256), 0, ctx->stream, d_keys, (uint32_t)n, d_partial);
+	hipLaunchKernelGGL(k_distinct_sum, dim3(1), dim3(256), 0, ctx->stream, d_partial, d_count);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
 }
