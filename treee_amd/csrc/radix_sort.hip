@@ -504,7 +504,7 @@ int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, ui
 
 // (one partial per workgroup, summed by the last-but-one step on 256 threads: thousands of atomics on ONE address are
 // memory-side operations that run one after the other -- 8 192 of them cost 0.2 ms, more than reading the 60 MB of keys)
-constexpr uint32_t DISTINCT_BLOCKS = 256;
+constexpr uint32_t DISTINCT_BLOCKS = 2048; // (256 workgroups -- one per CU -- took 0.2 ms for 15 M keys: 229 dependent trips per thread at one wave per SIMD)
 __global__ __launch_bounds__(256) void k_distinct(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ partial) {
 	__shared__ uint32_t s_w[4];
 	uint32_t c = 0;
@@ -517,7 +517,8 @@ __global__ __launch_bounds__(256) void k_distinct(const uint32_t *__restrict__ k
 }
 __global__ __launch_bounds__(256) void k_distinct_sum(const uint32_t *__restrict__ partial, uint32_t *__restrict__ count) {
 	__shared__ uint32_t s_w[4];
-	uint32_t c = partial[threadIdx.x];
+	uint32_t c = 0;
+	for (uint32_t b = threadIdx.x; b < DISTINCT_BLOCKS; b += 256u) c += partial[b];
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
 	if (lane_id() == 0) s_w[threadIdx.x >> 6] = c;
