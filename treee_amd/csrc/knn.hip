@@ -1330,7 +1330,9 @@ __global__ __launch_bounds__(256) void k_gather_rec(const float4 *__restrict__ s
 // every point), one key per cell, the cells' sizes scanned in Hilbert order, and one pass that moves every record to
 // cell destination + position inside the cell -- which also replaces the record gather (runs of a cell's records are
 // WRITTEN contiguously instead of single records being read from all over the cloud).  Same result as sort_pairs_dev on the
-// points' Hilbert indices, bit for bit; taken when K <= n / 2 (a uniform cloud has K ~ n and keeps the point sort).
+// points' Hilbert indices, bit for bit; taken when a sample of the keys promises K <= 0.4 n and the exact count confirms
+// K <= n / 2 (the 15 M / 200 m benchmark cloud has K ~ 0.8 n -- crowns are volumes -- and keeps the point sort; the 150 M /
+// 632 m one, whose cells are 3 times larger, takes this path).
 __global__ __launch_bounds__(256) void k_cell_heads(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ flag) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
@@ -1377,13 +1379,26 @@ __global__ __launch_bounds__(256) void k_cell_expand(const uint32_t *__restrict_
 	out_rec[d] = r;
 }
 
-int32_t hilbert_order_by_cells(treee_ctx *ctx, const SortedCloud *sc, uint32_t n_cells, SortedCloud *fine) {
+// *taken = false (and nothing written) when the exact count shows more than n / 2 occupied cells after all
+int32_t hilbert_order_by_cells(treee_ctx *ctx, const SortedCloud *sc, SortedCloud *fine, bool *taken) {
 	const uint32_t n = (uint32_t)sc->n;
 	hipStream_t st = ctx->stream;
 	uint32_t *d_flag = nullptr, *d_cid = nullptr, *d_start = nullptr, *d_hkey = nullptr, *d_hsorted = nullptr, *d_order = nullptr, *d_len = nullptr,
-	         *d_dsorted = nullptr, *d_dest = nullptr;
+	         *d_dsorted = nullptr, *d_dest = nullptr, *d_total = nullptr;
+	*taken = false;
 	TREEE_TRY(ctx->alloc_t(n, &d_flag));
 	TREEE_TRY(ctx->alloc_t(n, &d_cid));
+	TREEE_TRY(ctx->alloc_t(1, &d_total));
+	hipLaunchKernelGGL(k_cell_heads, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, n, d_flag);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_flag, d_cid, n, d_total));
+	// the number of cells sizes their sort: one host round trip of this path's own (it saves milliseconds where it is taken)
+	uint32_t *h = ctx->h_scalars;
+	TREEE_HIP(hipMemcpyAsync(h + 10, d_total, 4, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipStreamSynchronize(st));
+	const uint32_t n_cells = h[10];
+	if (n_cells == 0 || (uint64_t)n_cells * 2u > n) return TREEE_OK;
+	*taken = true;
 	TREEE_TRY(ctx->alloc_t((size_t)n_cells + 1, &d_start));
 	TREEE_TRY(ctx->alloc_t(n_cells, &d_hkey));
 	TREEE_TRY(ctx->alloc_t(n_cells, &d_hsorted));
@@ -1391,9 +1406,6 @@ int32_t hilbert_order_by_cells(treee_ctx *ctx, const SortedCloud *sc, uint32_t n
 	TREEE_TRY(ctx->alloc_t(n_cells, &d_len));
 	TREEE_TRY(ctx->alloc_t(n_cells, &d_dsorted));
 	TREEE_TRY(ctx->alloc_t(n_cells, &d_dest));
-	hipLaunchKernelGGL(k_cell_heads, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, n, d_flag);
-	TREEE_LAUNCH_CHECK();
-	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_flag, d_cid, n, nullptr));
 	hipLaunchKernelGGL(k_cell_emit, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, d_flag, d_cid, n, n_cells, d_start, d_hkey);
 	TREEE_LAUNCH_CHECK();
 	TREEE_TRY(sort_pairs_dev(ctx, d_hkey, nullptr, n_cells, 30, d_hsorted, d_order)); // (distinct keys: no ties to keep stable)
@@ -1450,10 +1462,13 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_perm));
 	TREEE_TRY(pool_alloc_t(ctx, n, &fine->d_sorted));
 	static const bool no_cells = getenv("TREEE_KNN_NO_CELLSORT") != nullptr; // A/B and test hook: always sort the points
-	if (!flag && !morton_order && !sc->hilbert && !no_cells && sc->n_cells > 0 && (uint64_t)sc->n_cells * 2u <= n) {
-		TREEE_TRY(hilbert_order_by_cells(ctx, sc.get(), (uint32_t)sc->n_cells, fine.get()));
-		*out = fine;
-		return TREEE_OK;
+	if (!flag && !morton_order && !sc->hilbert && !no_cells && sc->cell_share >= 0.0f && sc->cell_share <= 0.4f) {
+		bool taken = false;
+		TREEE_TRY(hilbert_order_by_cells(ctx, sc.get(), fine.get(), &taken));
+		if (taken) {
+			*out = fine;
+			return TREEE_OK;
+		}
 	}
 	uint32_t *d_lo = nullptr, *d_lo_s = nullptr, *d_pos1 = nullptr, *d_hi = nullptr, *d_pos2 = nullptr;
 	TREEE_TRY(ctx->alloc_t(n, &d_hi));

@@ -225,9 +225,9 @@ int32_t build_octree_on(treee_ctx *ctx, treee_octree *o) {
 	TREEE_TRY(long_run_flag_dev(ctx, o->sc->d_keys, n, d_crowded));
 	TREEE_HIP(hipMemcpyAsync(h + 0, d_crowded, 4, hipMemcpyDeviceToHost, st));
 	uint32_t *d_cells = nullptr; // occupied cells (distinct keys): lets that structure order cells instead of points
-	TREEE_TRY(ctx->alloc_t(1, &d_cells));
+	TREEE_TRY(ctx->alloc_t(2, &d_cells));
 	TREEE_TRY(distinct_keys_dev(ctx, o->sc->d_keys, n, d_cells));
-	TREEE_HIP(hipMemcpyAsync(h + 8, d_cells, 4, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipMemcpyAsync(h + 8, d_cells, 8, hipMemcpyDeviceToHost, st));
 	TREEE_TRY(cube_fetch_async(ctx, o->sc.get(), h_cube));
 	TREEE_HIP(hipMemcpyAsync(h + 1, d_lvl + 2 * DEPTH, 8, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipMemcpyAsync(h + 3, d_total, 4, hipMemcpyDeviceToHost, st));
@@ -236,7 +236,7 @@ int32_t build_octree_on(treee_ctx *ctx, treee_octree *o) {
 	o->n_nodes = (uint64_t)h[1] + h[2];
 	o->n_lod = lod_total;
 	o->sc->crowded = (int)h[0];
-	o->sc->n_cells = (int64_t)h[8];
+	o->sc->cell_share = h[9] ? (float)h[8] / (float)h[9] : 1.0f;
 	cube_commit(o->sc.get(), h_cube);
 	const uint32_t nn = (uint32_t)o->n_nodes;
 	TREEE_TRY(pool_alloc_t(ctx, n, &o->d_leaf));
@@ -623,14 +623,14 @@ int32_t treee_sort_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const flo
 		if (rc == TREEE_OK) rc = long_run_flag_dev(ctx, sc->d_keys, n, d_flag);
 		if (rc == TREEE_OK && hipMemcpyAsync(h, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "flag copy");
 		uint32_t *d_cells = nullptr;
-		if (rc == TREEE_OK) rc = ctx->alloc_t(1, &d_cells);
+		if (rc == TREEE_OK) rc = ctx->alloc_t(2, &d_cells);
 		if (rc == TREEE_OK) rc = distinct_keys_dev(ctx, sc->d_keys, n, d_cells);
-		if (rc == TREEE_OK && hipMemcpyAsync(h + 8, d_cells, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "cell count copy");
+		if (rc == TREEE_OK && hipMemcpyAsync(h + 8, d_cells, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "cell count copy");
 		if (rc == TREEE_OK) rc = cube_fetch_async(ctx, sc, h_cube);
 		if (rc == TREEE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_dev: synchronise");
 		if (rc == TREEE_OK) {
 			sc->crowded = (int)h[0];
-			sc->n_cells = (int64_t)h[8];
+			sc->cell_share = h[9] ? (float)h[8] / (float)h[9] : 1.0f;
 			cube_commit(sc, h_cube);
 		}
 	}

@@ -502,34 +502,40 @@ int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, ui
 	return TREEE_OK;
 }
 
-// (one partial per workgroup, summed by the last-but-one step on 256 threads: thousands of atomics on ONE address are
-// memory-side operations that run one after the other -- 8 192 of them cost 0.2 ms, more than reading the 60 MB of keys)
-constexpr uint32_t DISTINCT_BLOCKS = 2048; // (256 workgroups -- one per CU -- took 0.2 ms for 15 M keys: 229 dependent trips per thread at one wave per SIMD)
-__global__ __launch_bounds__(256) void k_distinct(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ partial) {
+// Share of distinct values among sorted keys, from a sample: one window of 256 consecutive keys out of every 16 (a 16th of
+// the array is read; each workgroup leaves one partial, no same-address atomics).  d_out[0] = distinct in the windows,
+// d_out[1] = keys in the windows.  Only a decision is taken from it (hilbert_order_by_cells counts exactly when it runs).
+constexpr uint32_t SAMPLE_EVERY = 16;
+__global__ __launch_bounds__(256) void k_distinct_sample(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ partial) {
 	__shared__ uint32_t s_w[4];
-	uint32_t c = 0;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) c += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+	const uint32_t i = blockIdx.x * (256u * SAMPLE_EVERY) + threadIdx.x;
+	uint32_t c = (i < n && (i == 0 || keys[i] != keys[i - 1])) ? 1u : 0u;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
 	if (lane_id() == 0) s_w[threadIdx.x >> 6] = c;
 	__syncthreads();
 	if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-__global__ __launch_bounds__(256) void k_distinct_sum(const uint32_t *__restrict__ partial, uint32_t *__restrict__ count) {
+__global__ __launch_bounds__(256) void k_distinct_sum(const uint32_t *__restrict__ partial, uint32_t blocks, uint32_t n, uint32_t *__restrict__ out) {
 	__shared__ uint32_t s_w[4];
 	uint32_t c = 0;
-	for (uint32_t b = threadIdx.x; b < DISTINCT_BLOCKS; b += 256u) c += partial[b];
+	for (uint32_t b = threadIdx.x; b < blocks; b += 256u) c += partial[b];
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
 	if (lane_id() == 0) s_w[threadIdx.x >> 6] = c;
 	__syncthreads();
-	if (threadIdx.x == 0) *count = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+	if (threadIdx.x == 0) {
+		out[0] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+		const uint32_t full = n / (256u * SAMPLE_EVERY), rest = n - full * 256u * SAMPLE_EVERY;
+		out[1] = full * 256u + (rest < 256u ? rest : 256u);
+	}
 }
-int32_t distinct_keys_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t *d_count) {
+int32_t distinct_keys_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t *d_out) {
+	const uint32_t blocks = div_up(n ? n : 1, 256u * SAMPLE_EVERY);
 	uint32_t *d_partial = nullptr;
-	TREEE_TRY(ctx->alloc_t(DISTINCT_BLOCKS, &d_partial));
-	hipLaunchKernelGGL(k_distinct, dim3(DISTINCT_BLOCKS), dim3(256), 0, ctx->stream, d_keys, (uint32_t)n, d_partial);
-	hipLaunchKernelGGL(k_distinct_sum, dim3(1), dim3(256), 0, ctx->stream, d_partial, d_count);
+	TREEE_TRY(ctx->alloc_t(blocks, &d_partial));
+	hipLaunchKernelGGL(k_distinct_sample, dim3(blocks), dim3(256), 0, ctx->stream, d_keys, (uint32_t)n, d_partial);
+	hipLaunchKernelGGL(k_distinct_sum, dim3(1), dim3(256), 0, ctx->stream, d_partial, blocks, (uint32_t)n, d_out);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
 }
