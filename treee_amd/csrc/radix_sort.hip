@@ -502,10 +502,10 @@ int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, ui
 	return TREEE_OK;
 }
 
-// Share of distinct values among sorted keys, from a sample: one window of 256 consecutive keys out of every 16 (a 16th of
+// Share of distinct values among sorted keys, from a sample: one window of 256 consecutive keys out of every 64 (a 64th of
 // the array is read; each workgroup leaves one partial, no same-address atomics).  d_out[0] = distinct in the windows,
 // d_out[1] = keys in the windows.  Only a decision is taken from it (hilbert_order_by_cells counts exactly when it runs).
-constexpr uint32_t SAMPLE_EVERY = 16;
+constexpr uint32_t SAMPLE_EVERY = 64;
 __global__ __launch_bounds__(256) void k_distinct_sample(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ partial) {
 	__shared__ uint32_t s_w[4];
 	const uint32_t i = blockIdx.x * (256u * SAMPLE_EVERY) + threadIdx.x;
