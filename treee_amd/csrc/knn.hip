@@ -1394,9 +1394,9 @@ int32_t hilbert_order_by_cells(treee_ctx *ctx, const SortedCloud *sc, SortedClou
 	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_flag, d_cid, n, d_total));
 	// the number of cells sizes their sort: one host round trip of this path's own (it saves milliseconds where it is taken)
 	uint32_t *h = ctx->h_scalars;
-	TREEE_HIP(hipMemcpyAsync(h + 10, d_total, 4, hipMemcpyDeviceToHost, st));
+	TREEE_HIP(hipMemcpyAsync(h + 12, d_total, 4, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipStreamSynchronize(st));
-	const uint32_t n_cells = h[10];
+	const uint32_t n_cells = h[12];
 	if (n_cells == 0 || (uint64_t)n_cells * 2u > n) return TREEE_OK;
 	*taken = true;
 	TREEE_TRY(ctx->alloc_t((size_t)n_cells + 1, &d_start));
