@@ -130,8 +130,10 @@ int32_t treee_knn_empty(const treee_knn *t, const float *q_xyz, uint64_t nq, flo
 
 /* kNN consumer: SegmentInformation::update curve branch (treee/src/calculations.rs:328-373,
  * fast_eigenvalues :467-498): curve_out[i] = 3*eig3/(eig1+eig2+eig3) of the covariance of the
- * k nearest neighbours (reference: k = 31, max_dist_sq = f32::MAX).  acos/cos differ between
- * libm and OCML: tolerance 1e-5 abs on curve, not bit-exact. */
+ * k nearest neighbours (reference: k = 31, max_dist_sq = f32::MAX).  acos / cos are the one
+ * definition of include/treee_f32_trig.h (f64 evaluation rounded once): `curve` is bit for bit what
+ * the reference's loop gives on the same neighbour list with a correctly rounding libm, and within
+ * a few 1e-7 of any libm's result; lists differ from the reference's only inside distance ties (H2). */
 int32_t treee_curvature(const float *xyz_aos, uint64_t n, uint32_t k, float max_dist_sq,
                         float *curve_out);
 int32_t treee_curvature_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
