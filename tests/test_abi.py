@@ -94,6 +94,42 @@ def test_argument_validation_needs_no_gpu():
     assert out[11] == -1.0 and out[15] == 0.0 and out[0] > 0
 
 
+def test_multi_gpu_entry_points_validate_their_arguments_without_a_gpu():
+    """the communicator and the sharded entry points refuse bad arguments before they touch a device (status INVALID /
+    UNSUPPORTED and a message, nothing unwinds); the plan arithmetic is pure host code and runs here"""
+    import treee_amd as T
+    from treee_amd import _lib
+
+    L = T.lib()
+    h = C.c_void_p()
+    assert L.treee_comm_create_host(None, 0, 1, C.byref(h)) == 1
+    ops = _lib.CommHostOps()  # null callbacks
+    assert L.treee_comm_create_host(C.byref(ops), 0, 1, C.byref(h)) == 1
+    assert L.treee_comm_create_rccl(None, 0, 1, 0, C.byref(h)) == 1
+    assert L.treee_comm_wrap_rccl(None, 0, 1, C.byref(h)) == 1
+    assert L.treee_comm_info(None, None, None, None) == 1
+    assert L.treee_comm_destroy(None) == 0 and L.treee_shard_plan_free(None) == 0
+    counts = np.zeros(8, np.uint32)
+    assert L.treee_shard_plan_create(counts.ctypes.data_as(C.c_void_p), 1, 0, 0, 0, C.byref(h)) == 1 and b"top_level" in L.treee_last_error()
+    assert L.treee_shard_plan_create(counts.ctypes.data_as(C.c_void_p), 1, 7, 0, 0, C.byref(h)) == 1
+    assert L.treee_shard_plan_create(None, 1, 1, 0, 0, C.byref(h)) == 1
+    assert L.treee_shard_plan_create(counts.ctypes.data_as(C.c_void_p), 1, 1, 0, 0, C.byref(h)) == 0
+    info = _lib.ShardPlanInfo()
+    assert L.treee_shard_plan_info_get(h, C.byref(info)) == 0 and info.n_total == 0 and info.leaf_cap == 256 and info.world == 1
+    rk = _lib.ShardPlanRank()
+    assert L.treee_shard_plan_rank_get(h, 1, C.byref(rk)) == 1 and L.treee_shard_plan_rank_get(h, 0, C.byref(rk)) == 0 and rk.count == 0
+    assert L.treee_shard_plan_levels(h, None, None, 0, None) == 1
+    L.treee_shard_plan_free(h)
+    assert L.treee_shard_octree_build_dev(None, None, None, 0, None, 0.0, 0, 0, 0, C.byref(h)) == 1
+    assert L.treee_shard_octree_info_get(None, None, None, None) == 1
+    assert L.treee_shard_exchange_ghosts_dev(None, None, None, 0, None, 0, 1.0, 0, 0, None, None) == 1
+    assert L.treee_frame_reduce_min_dev(None, None, None, 0) == 1
+    assert L.treee_shard_cube_dev(None, None, None, 0, None, None) == 1
+    assert L.treee_splat_octree_dev(None, None, None, None, None, 0.1, 0, 0xFFFFFFFF, 4, 4, None, 0, 0, None, None) == 1
+    pts, seg, out = np.zeros((4, 3), np.float32), np.zeros(4, np.uint32), np.zeros(4, np.float32)
+    assert L.treee_curvature_segments_multi(None, 0, pts.ctypes.data_as(C.c_void_p), seg.ctypes.data_as(C.c_void_p), 4, 1, 31, 1.0, out.ctypes.data_as(C.c_void_p)) == 1
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "treee_amd")
     for dirpath, _, files in os.walk(pkg):
