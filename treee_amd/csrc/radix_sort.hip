@@ -19,10 +19,11 @@ namespace treee {
 
 constexpr int RS_BLOCK = 256;
 #ifndef TREEE_RS_ITEMS
-#define TREEE_RS_ITEMS 16
+#define TREEE_RS_ITEMS 20 // keys per thread; a multiple of 4 (16-byte loads).  12 / 16 / 20: structure stage 1.706 / 1.633 / 1.590 ms (round 3; round 2 had 24 at 1.05 vs 1.02 for 20)
 #endif
 constexpr int RS_ITEMS = TREEE_RS_ITEMS;
-constexpr int RS_TILE = RS_BLOCK * RS_ITEMS; // 4096 keys per workgroup
+constexpr int RS_TILE = RS_BLOCK * RS_ITEMS; // 5120 keys per workgroup
+static_assert(RS_ITEMS % 4 == 0, "rs_hist loads four keys at a time");
 
 // ---- Morton keys (quant10 / spread3: common.h) ----------------------------------------------
 __global__ __launch_bounds__(256) void k_morton_keys(const float *__restrict__ xyz, uint32_t n,
