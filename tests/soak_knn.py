@@ -4,7 +4,8 @@
 
 Clouds of 1 .. 70 000 points (cubes, planes, lines, clusters, lattices, duplicates; offsets up to 3e5), k from 1 to 100, four
 radii, queries on and off the points; every case through the SURVEY H2 contract (counts and distance bits identical, indices
-inside their tie groups).  Round 2: 31 000 cases, clean."""
+inside their tie groups), and the structure built over an octree against the one built from the points (identical answers).
+Round 2: 31 000 cases, clean."""
 import sys, time
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,5 +40,14 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 90:
         ties += check_knn_contract(p, q, g_ent, g_cnt, r_ent, r_cnt)
     except AssertionError as e:
         print('FAIL', n, shape, k, maxd, e); np.save(os.path.join(ROOT, 'gpurun_out', 'soak_fail.npy'), p); raise
+    # the structure over an octree's Morton-sorted cloud (its Hilbert order by cells where cells hold several points, by points
+    # otherwise: knn.hip hilbert_order_by_cells) must answer exactly like the one built from the raw points -- indices included
+    import torch
+    oc = T.Octree(torch.from_numpy(p).cuda())
+    t2 = T.KDTree.from_octree(oc)
+    h_ent, h_cnt = t2.k_nearest_batch(q, k, maxd)
+    if not (np.array_equal(h_cnt, g_cnt) and np.array_equal(h_ent['distance'].view(np.uint32), g_ent['distance'].view(np.uint32)) and np.array_equal(h_ent['index'], g_ent['index'])):
+        print('FAIL (octree structure differs from the point structure)', n, shape, k, maxd); np.save(os.path.join(ROOT, 'gpurun_out', 'soak_fail.npy'), p); raise SystemExit(1)
+    t2.close(); oc.close()
     tree.close(); cases += 1
 print('cases', cases, 'tie-resolved indices', ties)
