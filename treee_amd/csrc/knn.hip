@@ -1431,10 +1431,12 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 	*out = sc;
 	const uint64_t n = sc->n;
 	static const bool off = getenv("TREEE_KNN_NO_REFINE") != nullptr; // A/B and test hook
-	if (n <= LONG_RUN || off) return cube_to_host(ctx, sc.get());
+	if (off) return cube_to_host(ctx, sc.get());
 	hipStream_t st = ctx->stream;
 	uint32_t flag = 0;
-	if (sc->crowded >= 0) { // the octree build already asked (its own host round trip carried the answer)
+	if (n <= LONG_RUN) { // no cell can be crowded; the structure still gets ITS order (the tie rule names the Hilbert index:
+		TREEE_TRY(cube_to_host(ctx, sc.get())); // a small cloud must not answer ties differently when it comes through an octree)
+	} else if (sc->crowded >= 0) { // the octree build already asked (its own host round trip carried the answer)
 		flag = (uint32_t)sc->crowded;
 	} else {
 		uint32_t *d_flag = nullptr;
