@@ -200,7 +200,8 @@ def test_knn_structure_from_an_octree_orders_cells_like_the_point_sort(T):
     forest, _ = synth.forest_cloud(400_000, plot=30.0)
     dup = np.concatenate([forest[:50_000], forest[:50_000], forest[:10_000]])
     uniform = quantised_cloud(100_000, 17, extent=(2000, 2000, 2000))
-    for name, pts in (("forest", forest), ("duplicates", dup), ("uniform", uniform)):
+    lattice = (np.random.default_rng(3).integers(0, 12, (63, 3)) * 0.25).astype(np.float32)  # 63 points, many equal distances: small clouds too
+    for name, pts in (("forest", forest), ("duplicates", dup), ("uniform", uniform), ("lattice", lattice)):
         d_pts = torch.from_numpy(pts).cuda()
         oc = T.Octree(d_pts)
         a = T.KDTree.from_octree(oc)
