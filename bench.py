@@ -61,7 +61,41 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="points of the CPU-baseline sample (about 10-30 s of oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (ingest, per-segment kNN, eye-dome, out-of-core stream): profiling runs")
+    ap.add_argument("--dry-run", action="store_true", help="bring the ranks up, build the tile plan and the library's communicator, exchange a few words through it "
+                    "and print the JSON skeleton -- no GPU work (what the CPU suite runs: the launch path of --gpus N)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python3 bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): this process starts the N ranks
+    itself -- fresh child processes with the environment torch.distributed.run would give them -- and never touches the GPU
+    (nothing here or above calls into HIP; `import torch` does not).  Rank 0's JSON line reaches stdout through the inherited
+    descriptor.  A rank that dies takes the others down instead of leaving them in a collective."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TREEE_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                for other in live:  # (exactly the processes started above)
+                    other.terminate()
+    return rc
 
 
 class Stage:
@@ -87,12 +121,16 @@ class Stage:
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))  # before anything touches the GPU: the ranks are fresh processes
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # rehearsal knobs (NOT used by the driver): several ranks on one GPU over gloo
-    backend = os.environ.get("TREEE_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("TREEE_BENCH_BACKEND", "gloo" if args.dry_run else "nccl")
+    if args.dry_run:
+        return dry_run(args, rank, world, backend)
     if os.environ.get("TREEE_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -133,26 +171,20 @@ def main():
     if side is not None:
         ctx2.reserve(int(n * 1.15) * 24 + (32 << 20))  # node table, leaf ids, LOD lists and the scans' scratch of the side stream
     stages = Stage()
+    side_stages = Stage()  # events recorded on the side stream (torch's current stream inside `with torch.cuda.stream(side)`)
     halo = args.halo
     state = {}
     comm = None
     if world > 1:
         # the library's own communicator: RCCL over xGMI under the nccl backend (torch only carries the unique id), host
-        # callbacks over the torch group otherwise (gloo rehearsals) or when RCCL cannot be opened
+        # callbacks over the torch group otherwise (gloo rehearsals) or when some rank cannot open RCCL.  Comm.rccl agrees
+        # over the torch group before it initialises anything, so every rank takes the same branch here.
         if args.transport == "host" or (args.transport == "auto" and backend != "nccl"):
             comm = D.Comm.host()
+        elif args.transport == "rccl":
+            comm = D.Comm.rccl()
         else:
-            try:
-                comm = D.Comm.rccl()
-            except T.TreeeError as e:
-                if args.transport == "rccl":
-                    raise
-                print(f"# rank {rank}: RCCL transport unavailable ({e}); host-staged transport instead", file=sys.stderr)
-                comm = None
-            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must use the same transport
-            if int(ok.item()) == 0:
-                comm = D.Comm.host()
+            comm = D.Comm.auto()
 
     def step(record):
         nonlocal halo
@@ -204,16 +236,25 @@ def main():
         state["owned"] = int(oc.rank_info.count)
 
         # The environment culls nothing (min 0, max u32::MAX), so the packed (depth, index) frame depends on positions
-        # only: it is drawn now on the second stream and min-reduced there (RCCL: on that stream, under the kNN kernel of
-        # the first); the values are looked up by the resolve pass once the curvature exists.
+        # only: it is drawn now on the second stream and min-reduced there, i.e. beside the kNN structure's build (a dozen
+        # streaming launches that leave CUs free).  It does NOT overlap the kNN kernel: that kernel fills every CU (504 of
+        # 512 VGPRs per SIMD lane, profiles/README.md "Concurrency experiments"), so whatever of the reduce has not run
+        # when it starts runs after it -- the stage `frame_reduce_wait_resolve` is that remainder, timed, and the side
+        # stream's own duration is reported as `frame_draw_reduce_side_stream`.  (One communicator, two streams: the
+        # octree's all-to-all has completed -- the build ends with a synchronisation -- before the reduce is enqueued,
+        # and the next step's exchange comes after `resolve` has joined the side stream.)
         def draw():
             side.wait_stream(torch.cuda.current_stream())
-            T._lib.check(T.lib().treee_splat_dev(ctx2.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj),
-                                                 env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, rank * n, None, None))
-            D.frame_reduce_min(packed, comm, ctx2)
+            with torch.cuda.stream(side):
+                side_stages.run("frame_draw_reduce_side_stream", lambda: (
+                    T._lib.check(T.lib().treee_splat_dev(ctx2.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj),
+                                                         env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, rank * n, None, None)),
+                    D.frame_reduce_min(packed, comm, ctx2)), record)
 
         stages.run("splat_and_frame_reduce_enqueue", draw, record)
-        tree = stages.run("knn_build", lambda: T.KDTree.new(cloud, ctx), record)
+        # ONE Morton sort of the tile per step, as at N = 1: the sharded octree has the own points in Morton order of the
+        # common cube; the kNN structure merges the ghosts in with its own (Hilbert) sort (treee_knn_from_shard_dev)
+        tree = stages.run("knn_build", lambda: T.KDTree.from_shard(oc, cloud[n:], ctx), record)
         cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
         # only the shard's own points are queried: the ghosts behind them are neighbours, not queries
         stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv, n_own=n), record)
@@ -273,6 +314,8 @@ def main():
         D._all_reduce(t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms = stages.mean_ms()
+    ms.update(side_stages.mean_ms())
+    comm_info = comm.info() if comm is not None else None
 
     if rank == 0:
         total_points = n * world * args.steps
@@ -311,7 +354,9 @@ def main():
                 "framebuffer": [W, H],
                 "parallelism": f"spatial x/z tiles {D.tile_grid(world)[0]}x{D.tile_grid(world)[1]}, ghost all-gather halo {halo} m; sharded octree (common cube, "
                                f"Morton-cell ownership: rank 0 holds {n} points and owns {state.get('owned')} of the sorted order)" if world > 1 else "one GPU",
-                "transport": None if comm is None else ("rccl" if comm.is_rccl else "host-staged callbacks over the torch group"),
+                "transport": None if comm is None else ("rccl" if comm_info[2] else "host-staged callbacks over the torch group"),
+                "comm_ranks": None if comm is None else comm_info[1],  # what the library's communicator itself reports (treee_comm_info)
+                "launched_by": "bench.py (spawned its own ranks)" if os.environ.get("TREEE_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "python"),
                 "total_points": n * world,
                 "halo_verified": halo_verified,
             },
@@ -322,8 +367,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": measured_traffic(m_knn),
-                "valu_busy": measured_valu_busy(m_knn),
+                **committed_counters(m_knn),
                 "algorithmic_bytes_per_point": BYTES["knn_curve"],
                 "points_per_launch": m_knn,
                 "kernel_ms": round(knn_ms, 3),
@@ -346,6 +390,39 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
         print(json.dumps(out), flush=True)
     free_state()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dry_run(args, rank, world, backend):
+    """The launch path of `--gpus N` without a GPU (tests/test_host_logic.py runs it with two ranks): rendezvous over
+    `backend`, the tile plan, the library's communicator (host callbacks over the group -- RCCL needs devices), a shard plan
+    computed by every rank from all-gathered counts, and rank 0's JSON skeleton.  No hot-path work, no `value`."""
+    if world > 1:
+        dist.init_process_group(backend)
+    import treee_amd as T
+    from treee_amd import distributed as D
+
+    T.lib()
+    comm = D.Comm.host()
+    info = comm.info()
+    # a few words through the torch group the callbacks ride on, and the library's plan arithmetic on them
+    counts = np.zeros((world, 8), np.uint32)
+    counts[rank, rank % 8] = 1000 + rank
+    if world > 1:
+        t = torch.from_numpy(counts.view(np.int32).copy())
+        dist.all_reduce(t)
+        counts = t.numpy().view(np.uint32)
+    plan = D.ShardPlan(counts, 1)
+    owned = [int(plan.rank(r).count) for r in range(world)]
+    plan.close()
+    comm.close()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "Mpoints/s octree+kNN+splat", "value": None, "unit": "Mpoints/s", "n_gpus": world,
+                          "config": {"parallelism": f"spatial x/z tiles {D.tile_grid(world)[0]}x{D.tile_grid(world)[1]}", "comm_ranks": info[1],
+                                     "transport": "host-staged callbacks over the torch group", "owned_points_per_rank": owned,
+                                     "launched_by": "bench.py (spawned its own ranks)" if os.environ.get("TREEE_BENCH_SPAWNED") else "torch.distributed.run"}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -641,30 +718,33 @@ def _latest_profile(pattern):
     return best
 
 
-def measured_valu_busy(points):
-    """What actually bounds the kernel (it is not HBM): fraction of SIMD cycles that issue a VALU instruction, from the
-    committed SQ counters (profiles/knn_pmc.sh): SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is the share of ONE wave's lifetime,
-    a SIMD holds 3 waves of this kernel."""
-    try:
-        c = json.load(open(_latest_profile("knn_sq_pmc.json")))
-        if points != 15_000_000:
-            return None
-        return round(3.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3)
-    except Exception:
-        return None
+def committed_counters(points):
+    """`traffic` (HBM bytes per launch: 2 x FETCH_SIZE raw -- the gfx950 correction of MI355X_MICROARCH.md -- + WRITE_SIZE) and
+    `valu_busy` (share of SIMD issue cycles that issue a VALU instruction: waves per SIMD x SQ_ACTIVE_INST_VALU /
+    SQ_WAVE_CYCLES) of the dominant kernel.  PMC passes cannot run inside this process (rocprofv3 wraps the command), so both
+    come from the newest COMMITTED summaries (profiles/collect.sh, profiles/knn_pmc.sh) -- and only if those are not older
+    than the kernel: each file records the sha256 of csrc/knn.hip it was measured with, and a summary of another kernel
+    source (or of another cloud size) gives null.  The files used are named beside the numbers."""
+    import hashlib
 
-
-def measured_traffic(points):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN[_vM]_traffic.json: 2 x FETCH_SIZE raw, the gfx950 correction of MI355X_MICROARCH.md, + WRITE_SIZE);
-    only valid for the profiled size."""
+    out = {"traffic": None, "valu_busy": None, "counters_from": None}
     try:
-        t = json.load(open(_latest_profile("traffic.json")))
-        if t["points_per_launch"] == points:
-            return int(2 * t["fetch_size_bytes_raw"] + t["write_size_bytes"])
-    except Exception:
-        pass
-    return None
+        sha = hashlib.sha256(open(os.path.join(ROOT, "treee_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()[:16]
+        used = {}
+        tp = _latest_profile("traffic.json")
+        t = json.load(open(tp))
+        if t.get("knn_hip_sha16") == sha and t["points_per_launch"] == points:
+            out["traffic"] = int(2 * t["fetch_size_bytes_raw"] + t["write_size_bytes"])
+            used["traffic"] = os.path.basename(tp)
+        cp = _latest_profile("knn_sq_pmc.json")
+        c = json.load(open(cp))
+        if c.get("knn_hip_sha16") == sha and c.get("points_per_launch", 15_000_000) == points:
+            out["valu_busy"] = round(float(c.get("waves_per_simd", 3)) * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3)
+            used["valu_busy"] = os.path.basename(cp)
+        out["counters_from"] = used or f"stale: newest committed summaries ({os.path.basename(tp)}, {os.path.basename(cp)}) were not measured with this csrc/knn.hip ({sha})"
+    except Exception as e:
+        out["counters_from"] = f"unavailable: {type(e).__name__}"
+    return out
 
 
 def cpu_baseline(sample):

@@ -89,6 +89,13 @@ int32_t treee_knn_build_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, 
 /* kNN structure over the cloud an octree has already Morton-sorted (shares the sorted arrays
  * by reference count: one sort feeds both; either handle may be freed first) */
 int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_knn **out);
+/* The same for one rank of a sharded cloud: `o` is the rank's sharded octree (treee_shard_octree_build_dev), which holds
+ * the rank's own points in Morton order of the common cube; the structure is laid over those points followed by the
+ * `g` ghost points (own point i is the handle's point i, ghost j its point n_own + j: the layout of
+ * treee_shard_exchange_ghosts_dev's buffer), without sorting the tile a second time.  Cell keys -- and with them the
+ * order inside distance ties -- are those of the whole cloud's cube.  Serves treee_curvature_own_dev / treee_knn_self_dev
+ * and position queries.  No reference counterpart (the reference is one process). */
+int32_t treee_knn_from_shard_dev(treee_ctx *ctx, const treee_octree *o, const float *d_ghost_xyz_aos, uint64_t n_ghosts, treee_knn **out);
 /* One structure for a cloud that is cut into segments the way the reference holds it after segmentation
  * (`segment: Vec<u32>` beside the points, treee/src/calculations.rs:97-118): every segment behaves as its own
  * KDTree::new(&segment_points) (calculations.rs:329, 392-403) -- a self query only ever returns points of the
@@ -352,6 +359,11 @@ typedef struct {
 	int32_t (*all_reduce_min_u64)(void *user, uint64_t *buf, uint64_t count);
 } treee_comm_host_ops;
 int32_t treee_comm_create_host(const treee_comm_host_ops *ops, int32_t rank, int32_t world, treee_comm **out);
+/* TREEE_OK iff librccl can be opened and holds every entry point the RCCL transport uses.  Local and non-collective: each
+ * rank asks for itself, the ranks agree on the answer (e.g. a MIN all-reduce of a flag over whatever carries the unique
+ * id), and only then does rank 0 create the id and everybody enter treee_comm_create_rccl -- a rank that finds no RCCL
+ * must never leave the others waiting inside ncclCommInitRank. */
+int32_t treee_rccl_available(void);
 /* ncclGetUniqueId on one rank; the caller brings the 128 bytes to the others */
 int32_t treee_rccl_unique_id(uint8_t id_out[128]);
 /* ncclCommInitRank on `device` (collective: every rank calls it) */

@@ -5,7 +5,15 @@
 writes gpurun_out/<tag>/<tag>_kernel_stats.csv (library kernels only), <tag>_hbm_pmc.json (per-kernel FETCH_SIZE /
 WRITE_SIZE totals of one step, raw counter units = KB) and <tag>_traffic.json (the dominant kernel, per launch).
 """
-import csv, glob, json, os, re, sys
+import csv, glob, hashlib, json, os, re, sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def knn_sha16():
+    """what bench.py compares a committed summary with: the kernel source it was measured with"""
+    return hashlib.sha256(open(os.path.join(REPO, "treee_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()[:16]
+
 
 OURS = re.compile(r"\bk_[a-z]|\brs_[a-z]|\bos_(hist|pass)|treee::")
 
@@ -40,11 +48,12 @@ def main(root, tag):
     for e in pmc.values():
         e["calls"] = max(len(v) for v in e["calls"].values())
     json.dump(pmc, open(os.path.join(root, f"{tag}_hbm_pmc.json"), "w"), indent=1, sort_keys=True)
-    knn = next((v for k, v in pmc.items() if k.startswith("k_knn_sorted32")), None)
+    name, knn = max(((k, v) for k, v in pmc.items() if k.startswith("k_knn_")), key=lambda kv: kv[1].get("FETCH_SIZE_KB_total", 0.0), default=(None, None))
     if knn:
         n = knn["calls"]
         traffic = {
-            "kernel": "k_knn_sorted32",
+            "kernel": name,
+            "knn_hip_sha16": knn_sha16(),
             "points_per_launch": 15000000,
             "launches_in_pass": n,
             "fetch_size_bytes_raw": knn.get("FETCH_SIZE_KB_total", 0.0) * 1024 / n,

@@ -1275,6 +1275,37 @@ def _shard_worker(rank, world, port, out_dir, backend="gloo"):
     d, _, c = tree.self_neighbors_dev(31)
     ok = D.halo_is_sufficient(pts, d[:n, 30], bounds, halo, rank, world)
     curve = tree.curvature_dev(31, n_own=n)
+    # the same structure WITHOUT a second sort of the tile (bench.py's N > 1 step): the sharded octree holds the own points in
+    # Morton order of the common cube, the ghosts are merged in by the structure's own (Hilbert) sort (treee_knn_from_shard_dev)
+    comm = D.Comm.host() if backend == "gloo" else D.Comm.auto()
+    so = T.ShardedOctree(pts, comm, ctx=ctx)
+    tree2 = T.KDTree.from_shard(so, cloud[n:], ctx)
+    assert len(tree2) == cloud.shape[0]
+    d2, i2, c2 = tree2.self_neighbors_dev(31)
+    _, i1, _ = tree.self_neighbors_dev(31)
+    curve2 = tree2.curvature_dev(31, n_own=n)
+    # exact search: the distances cannot depend on the order the structure was cut in; indices may differ inside distance ties
+    # only (the common cube names other cells than the tile's own cube), and then the other index is equally far
+    assert torch.equal(d2.view(torch.int32), d.view(torch.int32)) and torch.equal(c2, c)
+    differ = (i2 != i1).nonzero()
+    if differ.shape[0]:
+        q, slot = differ[:, 0], differ[:, 1]
+        a, b = cloud[i2[q, slot].long()] - cloud[q], cloud[i1[q, slot].long()] - cloud[q]
+        da = (a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2]
+        db = (b[:, 0] * b[:, 0] + b[:, 1] * b[:, 1]) + b[:, 2] * b[:, 2]
+        assert torch.equal(da.view(torch.int32), db.view(torch.int32))
+    assert differ.shape[0] < 0.001 * d.numel()
+    same_rows = (i2[:n] == i1[:n]).all(1)
+    assert torch.equal(curve2[same_rows].view(torch.int32), curve[same_rows].view(torch.int32)) and int(same_rows.sum()) > 0.99 * n
+    # (x tiles interleave in Morton order, so points change hands in both builds and the octree keeps the rank's local sort
+    # beside its owned range; the world = 1 test below covers the build in which nothing moves)
+    so_m = T.ShardedOctree(pts, comm, ctx=ctx, top_level=2)
+    tree3 = T.KDTree.from_shard(so_m, cloud[n:], ctx)
+    d3, _, c3 = tree3.self_neighbors_dev(31)
+    assert torch.equal(d3.view(torch.int32), d.view(torch.int32)) and torch.equal(c3, c)
+    for hnd in (tree2, tree3, so, so_m):
+        hnd.close()
+    comm.close()
     # the shard's part of the frame, drawn without values and min-reduced over the ranks (bench.py's N > 1 step)
     w, h = 240, 135
     view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 45.0))
@@ -1381,6 +1412,21 @@ def test_sharded_octree_of_one_rank_is_the_octree(T, oracle, n, top_level, leaf_
     _assert_assembles_to(T, oracle, [so.piece()], pts, corner, size, leaf_cap, 32)
     with pytest.raises(T.TreeeError):
         T.KDTree.from_octree(so)  # global indices: no kNN structure over a shard
+    # ... but one over the rank's own points (+ ghosts: none here), from the sort the build already did (nothing moved, so the
+    # owned range IS the local sort); a ghost-less world of one must answer like the plain structure, index for index
+    d_pts = torch.from_numpy(pts).cuda()
+    t_shard, t_plain = T.KDTree.from_shard(so, d_pts[:0]), T.KDTree.new(d_pts)
+    k = min(31, n)
+    (d1, i1, c1), (d0, i0, c0) = t_shard.self_neighbors_dev(k), t_plain.self_neighbors_dev(k)
+    assert torch.equal(d1.view(torch.int32), d0.view(torch.int32)) and torch.equal(c1, c0) and torch.equal(i1, i0)
+    # a few of the cloud's own points handed in as "ghosts" are points n, n + 1, ... of the structure: each finds its twin at distance 0
+    if n >= 64:
+        t_g = T.KDTree.from_shard(so, d_pts[:40])
+        dg, _, _ = t_g.self_neighbors_dev(2)
+        assert len(t_g) == n + 40 and bool((dg[n:, :2] == 0).all()) and bool((dg[:40, :2] == 0).all())
+        t_g.close()
+    t_shard.close()
+    t_plain.close()
     so.close()
     comm.close()
 

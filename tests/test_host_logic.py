@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_synth_is_deterministic_and_shardable():
     from treee_amd import synth
@@ -378,3 +380,67 @@ def test_shard_plan_edge_cases():
     assert empty.info.n_total == 0 and empty.info.n_top_nodes == 0 and empty.rank(1).count == 0
     with pytest.raises(TreeeError):
         D.ShardPlan(np.zeros((2, 1), np.uint32), 0)
+
+
+# ---- the launch path of `bench.py --gpus N` and the transport agreement ---------------------
+def test_bench_starts_its_own_ranks_from_a_bare_python():
+    """`python3 bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent spawns the ranks before it touches a GPU
+    (here there is none), the ranks rendezvous over gloo on 127.0.0.1, build the library's communicator and a shard plan,
+    and rank 0 prints ONE JSON line.  --dry-run: everything of the N > 1 step that needs no device."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["config"]["comm_ranks"] == 2
+    assert d["config"]["owned_points_per_rank"] == [1000, 1001] and "spawned" in d["config"]["launched_by"]
+    # a rank that fails takes the job down with a non-zero code instead of leaving the other in a collective
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, TREEE_HIP_LIB="/nonexistent/libtreee_hip.so"))
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def _rccl_agreement_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if rank == 1:
+        os.environ["TREEE_RCCL_LIB"] = "/nonexistent/librccl.so.1"  # this rank has no RCCL; the other one does
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from treee_amd import _lib
+    from treee_amd import distributed as D
+
+    probe = _lib.lib().treee_rccl_available()
+    raised = None
+    try:
+        D.Comm.rccl()
+    except _lib.TreeeError as e:
+        raised = str(e)
+    comm = D.Comm.auto()  # every rank lands on the host transport
+    info = comm.info()
+    comm.close()
+    torch.save({"probe": probe, "raised": raised, "info": info}, os.path.join(out_dir, f"a{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_transport_before_any_collective_init(tmp_path):
+    """one rank cannot open librccl.  Every rank probes for itself (treee_rccl_available: no collective),
+    the flags are MIN-reduced, and ALL ranks raise / fall back together -- nobody waits in a broadcast or inside
+    ncclCommInitRank for a rank that has given up.  (Joined with a timeout: the old protocol hung here.)"""
+    world = 2
+    ctx = mp.spawn(_rccl_agreement_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=False)
+    import time
+
+    t0 = time.time()
+    while not ctx.join(timeout=1.0):
+        assert time.time() - t0 < 240, "the ranks are waiting for each other"
+    res = [torch.load(os.path.join(tmp_path, f"a{r}.pt")) for r in range(world)]
+    assert res[1]["probe"] != 0
+    assert res[0]["raised"] is not None and res[1]["raised"] is not None
+    assert "another rank" in res[0]["raised"] or res[0]["probe"] != 0
+    assert "this rank" in res[1]["raised"]
+    assert res[0]["info"] == (0, 2, False) and res[1]["info"] == (1, 2, False)

@@ -77,6 +77,7 @@ SYMBOLS = {
     "treee_knn_build": (_i32, [_vp, _u64, _pp]),
     "treee_knn_build_dev": (_i32, [_vp, _vp, _u64, _pp]),
     "treee_knn_from_octree_dev": (_i32, [_vp, _vp, _pp]),
+    "treee_knn_from_shard_dev": (_i32, [_vp, _vp, _vp, _u64, _pp]),
     "treee_knn_build_segments_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, C.POINTER(_vp)]),
     "treee_knn_free": (_i32, [_vp]),
     "treee_knn_len": (_i32, [_vp, C.POINTER(_u64)]),
@@ -119,6 +120,7 @@ SYMBOLS = {
     "treee_segments_calculate_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "treee_display_values_dev": (_i32, [_vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "treee_comm_create_host": (_i32, [C.POINTER(CommHostOps), _i32, _i32, _pp]),
+    "treee_rccl_available": (_i32, []),
     "treee_rccl_unique_id": (_i32, [_vp]),
     "treee_comm_create_rccl": (_i32, [_vp, _i32, _i32, _i32, _pp]),
     "treee_comm_wrap_rccl": (_i32, [_vp, _i32, _i32, _pp]),

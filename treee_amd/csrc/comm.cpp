@@ -29,16 +29,20 @@ std::mutex g_rccl_mu;
 RcclApi g_rccl;
 
 // The copy the process already holds first (under PyTorch that is torch's own librccl: two RCCL copies in one process
-// would each bring their own transport state), then TREEE_RCCL_LIB, then the system's.
+// would each bring their own transport state), then the system's.  TREEE_RCCL_LIB names ONE library instead: it alone is
+// tried, and a path that cannot be opened means "no RCCL here" (how a host without xGMI peers -- or a test -- says so).
 int32_t rccl_api(const RcclApi **out) {
 	std::lock_guard<std::mutex> lk(g_rccl_mu);
 	if (!g_rccl.lib) {
 		void *h = nullptr;
 		const char *names[] = {"librccl.so.1", "librccl.so"};
+		if (const char *env = std::getenv("TREEE_RCCL_LIB")) {
+			h = dlopen(env, RTLD_NOW | RTLD_NOLOAD);
+			if (!h) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+			if (!h) return set_err(TREEE_ERR_UNSUPPORTED, "TREEE_RCCL_LIB=%s cannot be opened: %s", env, dlerror());
+		}
 		for (const char *nm : names)
 			if (!h) h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
-		if (!h)
-			if (const char *env = std::getenv("TREEE_RCCL_LIB")) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
 		for (const char *nm : names)
 			if (!h) h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
 		if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
@@ -189,6 +193,13 @@ int32_t treee_comm_create_host(const treee_comm_host_ops *ops, int32_t rank, int
 	c->world = world;
 	*out = c;
 	return TREEE_OK;
+}
+
+int32_t treee_rccl_available(void) {
+	// only opens the library and looks the entry points up: no communicator, no collective, nothing a peer has to answer --
+	// so that the ranks can agree on the transport BEFORE any of them enters ncclCommInitRank
+	const RcclApi *api = nullptr;
+	return rccl_api(&api);
 }
 
 int32_t treee_rccl_unique_id(uint8_t id_out[128]) {

@@ -336,6 +336,9 @@ int32_t cube_to_host(treee_ctx *ctx, SortedCloud *sc); // both, with a synchroni
 
 // is this octree handle a rank's piece of a sharded octree (octree.hip)?  Its indices are global: no kNN structure over it
 bool octree_is_shard(const treee_octree *o);
+// a sharded octree's copy of the rank's own input in Morton order of the common cube (records carry *index_base + input
+// position); null for an ordinary octree
+std::shared_ptr<SortedCloud> octree_shard_local(const treee_octree *o, uint32_t *index_base);
 // per-block partial boxes of a cloud: d_partial[grid][6] = (min.xyz, max.xyz) (radix_sort.hip)
 int32_t bbox_partials_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, float **d_partial_out, uint32_t *grid_out);
 

@@ -1322,6 +1322,25 @@ __global__ __launch_bounds__(256) void k_gather_rec(const float4 *__restrict__ s
 	perm[i] = __float_as_uint(r.w);
 }
 
+// records of a shard's kNN structure: position p of the concatenation [the rank's own Morton-sorted records | its ghosts in
+// input order] -> (x, y, z, LOCAL index): an own record carries index_base + input position, ghost j is point n_own + j
+__global__ __launch_bounds__(256) void k_gather_own_ghost(const float4 *__restrict__ own, uint32_t n_own, uint32_t index_base, const float *__restrict__ ghost_xyz,
+                                                           const uint32_t *__restrict__ pos, uint32_t m, float4 *__restrict__ dst, uint32_t *__restrict__ perm) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= m) return;
+	const uint32_t p = pos[i];
+	float4 r;
+	if (p < n_own) {
+		r = own[p];
+		r.w = __uint_as_float(__float_as_uint(r.w) - index_base);
+	} else {
+		const uint32_t j = p - n_own;
+		r = make_float4(ghost_xyz[3ull * j + 0], ghost_xyz[3ull * j + 1], ghost_xyz[3ull * j + 2], __uint_as_float(p));
+	}
+	dst[i] = r;
+	perm[i] = __float_as_uint(r.w);
+}
+
 // ---- Hilbert order of a Morton-sorted cloud by ordering CELLS instead of points ------------------------------------------------
 // The points of one 2^-10 cell share their Morton key and their Hilbert index, are contiguous in the Morton order and keep
 // their relative order (both sorts are stable by original index).  So the Hilbert order of the cloud is: the occupied cells
@@ -1774,6 +1793,64 @@ int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_k
 	if (rc == TREEE_OK) rc = refine_dense_cells(ctx, sc, &t->sc); // (a private, finer-sorted copy if a Morton cell is crowded)
 	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
 	if (rc == TREEE_OK) rc = use_end(ctx, sc->owner, &sc->sync);
+	if (rc != TREEE_OK) {
+		treee_knn_free(t);
+		return rc;
+	}
+	*out = t;
+	return TREEE_OK;
+}
+
+// The kNN structure of one rank of a sharded cloud -- own points followed by ghost points (treee_shard_exchange_ghosts_dev's
+// layout: the handle's point i is own point i for i < n_own, ghost i - n_own behind them) -- WITHOUT sorting the tile a
+// second time: the sharded octree build has the own points in Morton order of the common cube already, the structure's
+// order is (Hilbert index of the cell, index), and a stable sort by Hilbert index of [own in (Morton cell, index) order |
+// ghosts in index order] is exactly that order, because inside one cell the own points stand in index order and every
+// ghost index is larger.  So: Hilbert indices of the sorted own keys (a table walk per key), Morton + Hilbert of the g
+// ghosts, ONE stable sort of n_own + g pairs, one gather.  Same arrays as treee_knn_build_dev over the concatenated cloud
+// would give with the common cube; only the cube (and with it the order inside distance ties) differs from that call's.
+int32_t treee_knn_from_shard_dev(treee_ctx *ctx, const treee_octree *o, const float *d_ghost_xyz, uint64_t g, treee_knn **out) {
+	if (!ctx || !o || !out || (g && !d_ghost_xyz)) return set_err(TREEE_ERR_INVALID, "treee_knn_from_shard_dev: null argument");
+	*out = nullptr;
+	uint32_t base = 0;
+	std::shared_ptr<SortedCloud> loc = octree_shard_local(o, &base);
+	if (!loc) return set_err(TREEE_ERR_INVALID, "treee_knn_from_shard_dev: not a sharded octree (treee_knn_from_octree_dev serves the others)");
+	const uint64_t n = loc->n, m = n + g;
+	if (m == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");
+	if (m >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per shard", (unsigned long long)m);
+	TREEE_HIP(hipSetDevice(ctx->device));
+	treee_knn *t = new treee_knn;
+	t->device = ctx->device;
+	t->n_points = m;
+	auto fine = std::make_shared<SortedCloud>();
+	fine->n = m;
+	fine->device = ctx->device;
+	fine->owner = ctx;
+	fine->size = loc->size;
+	fine->hilbert = true;
+	for (int a = 0; a < 3; ++a) fine->corner[a] = loc->corner[a];
+	t->sc = fine;
+	hipStream_t st = ctx->stream;
+	uint32_t *d_hk = nullptr, *d_pos = nullptr;
+	int32_t rc = ctx->reset();
+	if (rc == TREEE_OK) rc = use_begin(ctx, loc->owner, &loc->sync);
+	if (rc == TREEE_OK) rc = pool_alloc_t(ctx, m, &fine->d_keys);
+	if (rc == TREEE_OK) rc = pool_alloc_t(ctx, m, &fine->d_perm);
+	if (rc == TREEE_OK) rc = pool_alloc_t(ctx, m, &fine->d_sorted);
+	if (rc == TREEE_OK) rc = ctx->alloc_t(m, &d_hk);
+	if (rc == TREEE_OK) rc = ctx->alloc_t(m, &d_pos);
+	if (rc == TREEE_OK && n) rc = hilbert_keys_dev(ctx, loc->d_keys, nullptr, n, d_hk);
+	if (rc == TREEE_OK && g) rc = morton_keys_dev(ctx, d_ghost_xyz, g, loc->corner, loc->size, d_hk + n);
+	if (rc == TREEE_OK && g) rc = hilbert_keys_dev(ctx, d_hk + n, nullptr, g, d_hk + n);
+	if (rc == TREEE_OK) rc = sort_pairs_dev(ctx, d_hk, nullptr, m, 30, fine->d_keys, d_pos);
+	if (rc == TREEE_OK) {
+		hipLaunchKernelGGL(k_gather_own_ghost, dim3(div_up(m, 256)), dim3(256), 0, st, loc->d_sorted, (uint32_t)n, base, d_ghost_xyz, d_pos, (uint32_t)m, fine->d_sorted,
+		                   fine->d_perm);
+		if (hipGetLastError() != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_knn_from_shard_dev: gather launch");
+	}
+	if (rc == TREEE_OK) rc = use_end(ctx, loc->owner, &loc->sync);
+	if (rc == TREEE_OK) rc = refine_dense_cells(ctx, fine, &t->sc); // (crowded cells only: the cloud is in this structure's order already)
+	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
 	if (rc != TREEE_OK) {
 		treee_knn_free(t);
 		return rc;

@@ -30,6 +30,10 @@ struct treee_octree {
 	treee_shard_levels sh_levels{};
 	treee_octree_node *d_top_nodes = nullptr;
 	uint32_t *d_top_lod = nullptr;
+	// the rank's OWN input in Morton order of the common cube (step 1 of the sharded build; records carry global indices =
+	// index_base + input position): what a kNN structure over own + ghost points starts from instead of sorting the tile
+	// again (treee_knn_from_shard_dev).  Null when no point changed hands: `sc` then is that cloud.
+	std::shared_ptr<SortedCloud> sc_local;
 };
 // (the octree's own arrays are only ever touched by its owner's stream and by the caller through
 // treee_octree_dev_ptr, whose ordering is the caller's; the shared sorted cloud carries a HandleSync)
@@ -397,7 +401,8 @@ int32_t shard_build(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64
 	else
 		TREEE_TRY(shard_cube(ctx, comm, d_xyz, n, corner, &size));
 	// 1. the rank's input in (key, input order): the ordinary Morton sort with the common cube
-	SortedCloud local;
+	auto local_keep = std::make_shared<SortedCloud>();
+	SortedCloud &local = *local_keep;
 	TREEE_TRY(build_sorted_cloud(ctx, d_xyz, n, corner, size, &local));
 	// 2. points per level-L cell, all ranks
 	uint32_t *d_counts = nullptr;
@@ -562,6 +567,7 @@ int32_t shard_build(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64
 	}
 	TREEE_HIP(hipStreamSynchronize(st)); // (the uploads above read host vectors that end with this frame)
 	o->shard = true;
+	if (anything_moves) o->sc_local = local_keep; // (otherwise its arrays were handed to `sc` above)
 	return TREEE_OK;
 }
 
@@ -570,6 +576,11 @@ int32_t shard_build(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64
 namespace treee {
 std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o) { return o->sc; }
 bool octree_is_shard(const treee_octree *o) { return o && o->shard; }
+std::shared_ptr<SortedCloud> octree_shard_local(const treee_octree *o, uint32_t *index_base) {
+	if (!o || !o->shard) return nullptr;
+	*index_base = (uint32_t)o->sh_rank.index_base;
+	return o->sc_local ? o->sc_local : o->sc;
+}
 } // namespace treee
 
 extern "C" {
@@ -727,6 +738,7 @@ int32_t treee_octree_free(treee_octree *o) {
 	if (!o) return TREEE_OK;
 	(void)hipSetDevice(o->device);
 	o->sc.reset();
+	o->sc_local.reset();
 	pool_release(o->owner, o->d_nodes);
 	pool_release(o->owner, o->d_leaf);
 	pool_release(o->owner, o->d_lod);

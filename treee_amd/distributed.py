@@ -40,38 +40,87 @@ class Comm:
     def handle(self):
         return self._h
 
-    @property
-    def is_rccl(self):
+    def info(self):
+        """(rank, world, is_rccl) as the communicator itself reports them (treee_comm_info)"""
         import ctypes as C
 
         from . import _lib
 
-        flag = C.c_int32()
-        _lib.check(_lib.lib().treee_comm_info(self._h, None, None, C.byref(flag)))
-        return bool(flag.value)
+        r, w, flag = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().treee_comm_info(self._h, C.byref(r), C.byref(w), C.byref(flag)))
+        return int(r.value), int(w.value), bool(flag.value)
+
+    @property
+    def is_rccl(self):
+        return self.info()[2]
 
     @classmethod
     def rccl(cls, group=None, device=None):
+        """The library's RCCL communicator over `group`'s ranks.  Every step that can fail on ONE rank is followed by an
+        agreement over the torch group before the next collective step, so that all ranks raise together (and a caller can
+        fall back to `Comm.host` on all of them) instead of some waiting in a broadcast or inside ncclCommInitRank for a
+        rank that has already given up: (1) every rank probes librccl by itself (treee_rccl_available: no collective),
+        (2) rank 0 creates the unique id and broadcasts it with a status byte, (3) ncclCommInitRank, (4) the outcome."""
         import ctypes as C
 
         import numpy as np
 
         from . import _lib
 
-        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
-        uid = np.zeros(128, np.uint8)
+        live = dist.is_initialized()
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if live else (0, 1)
+        on_gpu = live and dist.get_backend(group) != "gloo"
+
+        def agree(ok, what):
+            """MIN over the ranks of a local success flag; raises the same error everywhere when any rank failed"""
+            msg = "" if ok else _lib.lib().treee_last_error().decode("utf-8", "replace")
+            if world > 1:
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+                if on_gpu:
+                    t = t.cuda()
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                all_ok = int(t.item()) == 1
+            else:
+                all_ok = bool(ok)
+            if not all_ok:
+                raise _lib.TreeeError(_lib.TREEE_ERR_UNSUPPORTED, f"RCCL transport: {what} failed on " + (f"this rank ({msg})" if not ok else "another rank"))
+
+        agree(_lib.lib().treee_rccl_available() == _lib.TREEE_OK, "opening librccl")
+        uid = np.zeros(129, np.uint8)  # [128] = rank 0's status
         if rank == 0:
-            _lib.check(_lib.lib().treee_rccl_unique_id(uid.ctypes.data_as(C.c_void_p)))
+            uid[128] = 1 if _lib.lib().treee_rccl_unique_id(uid.ctypes.data_as(C.c_void_p)) == _lib.TREEE_OK else 0
         if world > 1:
             t = torch.from_numpy(uid)
-            if dist.get_backend(group) != "gloo":
+            if on_gpu:
                 t = t.cuda()
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             uid = t.cpu().numpy()
+        if uid[128] != 1:  # (the same byte on every rank)
+            raise _lib.TreeeError(_lib.TREEE_ERR_UNSUPPORTED, "RCCL transport: ncclGetUniqueId failed on rank 0")
         dev = torch.cuda.current_device() if device is None else torch.device(device).index
         h = C.c_void_p()
-        _lib.check(_lib.lib().treee_comm_create_rccl(uid.ctypes.data_as(C.c_void_p), rank, world, dev, C.byref(h)))
+        rc = _lib.lib().treee_comm_create_rccl(np.ascontiguousarray(uid).ctypes.data_as(C.c_void_p), rank, world, dev, C.byref(h))
+        try:
+            agree(rc == _lib.TREEE_OK, "ncclCommInitRank")
+        except _lib.TreeeError:
+            if rc == _lib.TREEE_OK:
+                _lib.lib().treee_comm_destroy(h)
+            raise
         return cls(h, rank, world)
+
+    @classmethod
+    def auto(cls, group=None, device=None):
+        """RCCL when every rank of the group can open it, host callbacks over the group otherwise -- the same choice on
+        every rank (Comm.rccl agrees before it initialises anything)."""
+        from . import _lib
+
+        try:
+            return cls.rccl(group, device)
+        except _lib.TreeeError as e:
+            import sys
+
+            print(f"# treee: {e}; host-staged transport instead", file=sys.stderr)
+            return cls.host(group)
 
     @classmethod
     def host(cls, group=None):
@@ -157,7 +206,7 @@ class Comm:
     def for_group(cls, group=None):
         """RCCL when the group runs on it, host callbacks otherwise (gloo)."""
         if dist.is_initialized() and dist.get_backend(group) == "nccl":
-            return cls.rccl(group)
+            return cls.auto(group)
         return cls.host(group)
 
     def close(self):

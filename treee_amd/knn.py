@@ -71,6 +71,21 @@ class KDTree:
         self._h, self.n, self.device = h, int(octree.n_points), self.ctx.device
         return self
 
+    @classmethod
+    def from_shard(cls, sharded_octree, ghosts, ctx=None):
+        """kNN structure of one rank of a sharded cloud: the rank's own points (which `sharded_octree` already holds in
+        Morton order of the common cube) followed by `ghosts` (float32 [g, 3] on the device; may be empty) -- no second
+        sort of the tile (treee_knn_from_shard_dev).  Point i < n_own is own point i, n_own + j is ghost j."""
+        self = object.__new__(cls)
+        self.ctx = ctx or sharded_octree.ctx or default_context()
+        gh = dev_f32(ghosts, 3)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().treee_knn_from_shard_dev(self.ctx.handle, sharded_octree._h, ptr(gh) if gh.shape[0] else None, gh.shape[0], C.byref(h)))
+        n = C.c_uint64()
+        _lib.check(_lib.lib().treee_knn_len(h, C.byref(n)))
+        self._h, self.n, self.device = h, int(n.value), self.ctx.device
+        return self
+
     def __len__(self):
         return self.n
 
