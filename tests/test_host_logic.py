@@ -159,34 +159,59 @@ def _ghost_worker(rank, world, port, out_dir):
 
 
 def test_ipc_bincode_layout_and_round_trip():
-    """`.ipc` = bincode 1.3.3 defaults of InteractiveSave (interactive/mod.rs:44-50): a hand-assembled byte vector
-    (one segment with two points, an empty `deleted`) decodes to the expected values and re-encodes identically"""
+    """`.ipc` = bincode 1.3.3 defaults of InteractiveSave (interactive/mod.rs:44-50): hand-assembled byte vectors (one
+    segment with two points, an empty `deleted`) in BOTH layouts a nalgebra Point3 may have on disk -- "seq" (u64 length 3
+    before every point: what SURVEY section 8 F2 believes nalgebra 0.33's ArrayStorage does; the writer's default) and
+    "flat" (three coordinates only) -- decode to the expected values, are told apart by the reader, and re-encode
+    identically.  Neither is verified against a file the reference wrote (none exists here)."""
     import struct
 
     from treee_amd import ipc
 
     f32, f64, u32, u64 = (lambda *v: struct.pack("<%df" % len(v), *v)), (lambda *v: struct.pack("<%dd" % len(v), *v)), (
         lambda v: struct.pack("<I", v)), (lambda v: struct.pack("<Q", v))
-    seg = (u64(2) + f32(1.0, 2.0, 3.0, -4.5, 0.25, 8.0)  # points: Vec<Point3<f32>>: u64 length, 3 f32 each, no inner prefix
-           + u64(2) + u32(ipc.TRUNK) + u32(ipc.CROWN)    # classifications: u64 length, u32 variant index each
-           + f32(1.5, 2.5, 0.5, 3.5)                     # info: four f32 in declaration order
-           + f32(-4.5, 0.25, 3.0) + f32(1.0, 2.0, 8.0)   # min, max
-           + b"\x01" + f64(48.137, 11.575))             # coords: Some((f64, f64))
-    empty = u64(0) + u64(0) + f32(0, 0, 0, 0) + f32(0, 0, 0) + f32(0, 0, 0) + b"\x00"
     loc = "+proj=utm\n+ellps=GRS80\n+zone=32".encode()  # DEFAULT_LOCATION, interactive/mod.rs:53
-    blob = u64(1) + u32(0xDEADBEEF) + seg + empty + f64(500000.5, 120.25, -5300000.75) + u64(len(loc)) + loc
-    save = ipc.read_ipc(blob)
-    s = save["segments"][0xDEADBEEF]
-    assert s["points"].tolist() == [[1.0, 2.0, 3.0], [-4.5, 0.25, 8.0]] and s["classifications"].tolist() == [1, 2]
-    assert s["info"] == {"trunk_height": 1.5, "crown_height": 2.5, "ground_sep": 0.5, "crown_sep": 3.5}
-    assert s["coords"] == (48.137, 11.575) and save["deleted"]["coords"] is None and len(save["deleted"]["points"]) == 0
-    assert save["world_offset"].tolist() == [500000.5, 120.25, -5300000.75] and save["source_location"].startswith("+proj=utm")
-    assert ipc.write_ipc(save) == blob
-    pts, segment, ids = ipc.to_cloud(save)
-    assert pts.shape == (2, 3) and segment.tolist() == [0, 0] and ids == [0xDEADBEEF]
-    for bad in (blob[:-1], blob + b"\0", blob.replace(u32(ipc.CROWN), u32(7), 1)):
+
+    def blob_of(layout):
+        pre = u64(3) if layout == "seq" else b""  # serialize_seq(Some(3)) under bincode: a u64 length before the elements
+        p3 = lambda *v: pre + f32(*v)  # noqa: E731  (Point3<f32>)
+        seg = (u64(2) + p3(1.0, 2.0, 3.0) + p3(-4.5, 0.25, 8.0)  # points: Vec<Point3<f32>>: u64 length, then the points
+               + u64(2) + u32(ipc.TRUNK) + u32(ipc.CROWN)           # classifications: u64 length, u32 variant index each
+               + f32(1.5, 2.5, 0.5, 3.5)                            # info: four f32 in declaration order
+               + p3(-4.5, 0.25, 3.0) + p3(1.0, 2.0, 8.0)            # min, max
+               + b"\x01" + f64(48.137, 11.575))                    # coords: Some((f64, f64)): a tuple has no prefix
+        empty = u64(0) + u64(0) + f32(0, 0, 0, 0) + p3(0, 0, 0) + p3(0, 0, 0) + b"\x00"
+        return u64(1) + u32(0xDEADBEEF) + seg + empty + pre + f64(500000.5, 120.25, -5300000.75) + u64(len(loc)) + loc
+
+    blobs = {layout: blob_of(layout) for layout in ("seq", "flat")}
+    assert len(blobs["seq"]) == len(blobs["flat"]) + 8 * 7  # seven Point3 in the file: two points, min and max twice, world_offset
+    for layout, blob in blobs.items():
+        save = ipc.read_ipc(blob)
+        assert save["layout"] == layout
+        s = save["segments"][0xDEADBEEF]
+        assert s["points"].tolist() == [[1.0, 2.0, 3.0], [-4.5, 0.25, 8.0]] and s["classifications"].tolist() == [1, 2]
+        assert s["info"] == {"trunk_height": 1.5, "crown_height": 2.5, "ground_sep": 0.5, "crown_sep": 3.5}
+        assert s["min"].tolist() == [-4.5, 0.25, 3.0] and s["max"].tolist() == [1.0, 2.0, 8.0]
+        assert s["coords"] == (48.137, 11.575) and save["deleted"]["coords"] is None and len(save["deleted"]["points"]) == 0
+        assert save["world_offset"].tolist() == [500000.5, 120.25, -5300000.75] and save["source_location"].startswith("+proj=utm")
+        assert ipc.write_ipc(save) == blob  # written back in the layout it was read with
+        other = "flat" if layout == "seq" else "seq"
+        assert ipc.write_ipc(save, layout=other) == blobs[other]  # ... or converted
+        assert ipc.read_ipc(blob, layout=layout)["layout"] == layout
         with pytest.raises(ValueError):
-            ipc.read_ipc(bad)
+            ipc.read_ipc(blob, layout=other)
+        pts, segment, ids = ipc.to_cloud(save)
+        assert pts.shape == (2, 3) and segment.tolist() == [0, 0] and ids == [0xDEADBEEF]
+        for bad in (blob[:-1], blob + b"\0", blob.replace(u32(ipc.CROWN), u32(7), 1)):
+            with pytest.raises(ValueError):
+                ipc.read_ipc(bad)
+    # a project assembled here (no layout recorded) is written in the sequence form
+    fresh = {k: v for k, v in ipc.read_ipc(blobs["flat"]).items() if k != "layout"}
+    assert ipc.write_ipc(fresh) == blobs["seq"]
+    # a point whose length prefix is not 3 is refused in the sequence form (and the file is not a flat one either)
+    broken = blobs["seq"].replace(u64(3) + f32(1.0, 2.0, 3.0), u64(4) + f32(1.0, 2.0, 3.0), 1)
+    with pytest.raises(ValueError):
+        ipc.read_ipc(broken)
 
 
 def test_partition_segments_is_balanced_and_deterministic():
