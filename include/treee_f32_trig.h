@@ -29,8 +29,22 @@
 #define TREEE_TRIG_SQRT(x) sqrt(x)
 #endif
 
+/* No fused multiply-add inside these functions, whatever the includer's flags: clang / hipcc -- where the
+ * device always has an FMA to contract into -- switch contraction off per function body (the setting is recorded on every
+ * floating-point instruction and survives inlining); other compilers are refused on a target that has FMA instructions
+ * unless the build says it passes -ffp-contract=off (-DTREEE_TRIG_CONTRACT_OFF; oracle/Makefile does both). */
+#if defined(__clang__)
+#define TREEE_TRIG_NOFMA _Pragma("clang fp contract(off)")
+#else
+#define TREEE_TRIG_NOFMA
+#if defined(__FMA__) && !defined(TREEE_TRIG_CONTRACT_OFF)
+#error "treee_f32_trig.h: this target has FMA instructions -- compile with -ffp-contract=off and -DTREEE_TRIG_CONTRACT_OFF"
+#endif
+#endif
+
 /* (asin(x) - x) / x as a function of z = x * x, |x| <= 0.5 */
 TREEE_TRIG_FN double treee_trig_asin_r(double z) {
+	TREEE_TRIG_NOFMA
 	const double pS0 = 1.66666666666666657415e-01, pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
 	             pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04, pS5 = 3.47933107596021167570e-05,
 	             qS1 = -2.40339491173441421878e+00, qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
@@ -42,6 +56,7 @@ TREEE_TRIG_FN double treee_trig_asin_r(double z) {
 
 /* acos for an f32 argument, rounded once.  |x| > 1 or NaN -> NaN (the caller clamps: calculations.rs:487-493). */
 TREEE_TRIG_FN float treee_acos_f32(float xf) {
+	TREEE_TRIG_NOFMA
 	const double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17, pi = 3.14159265358979311600e+00;
 	const double x = (double)xf;
 	if (!(x >= -1.0 && x <= 1.0)) return (float)((x - x) / (x - x));
@@ -58,6 +73,7 @@ TREEE_TRIG_FN float treee_acos_f32(float xf) {
 }
 
 TREEE_TRIG_FN double treee_trig_ksin(double x) { /* |x| <= pi/4 */
+	TREEE_TRIG_NOFMA
 	const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
 	             S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
 	const double z = x * x, v = z * x;
@@ -65,6 +81,7 @@ TREEE_TRIG_FN double treee_trig_ksin(double x) { /* |x| <= pi/4 */
 	return x + v * (S1 + z * r);
 }
 TREEE_TRIG_FN double treee_trig_kcos(double x) { /* |x| <= pi/4 */
+	TREEE_TRIG_NOFMA
 	const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
 	             C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
 	const double z = x * x;
@@ -76,6 +93,7 @@ TREEE_TRIG_FN double treee_trig_kcos(double x) { /* |x| <= pi/4 */
 /* cos for an f32 argument, rounded once.  The path only ever passes [0, pi + 2^-21]; the reduction is exact enough for
  * correct rounding up to |x| = 1e5 (three-piece pi/2); beyond that, NaN and inf the result is NaN. */
 TREEE_TRIG_FN float treee_cos_f32(float xf) {
+	TREEE_TRIG_NOFMA
 	const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, /* first 33 bits of pi/2 */
 	             pio2_2 = 6.07710050630396597660e-11,                                        /* next 33 bits */
 	             pio2_3 = 2.02226624871116645580e-21, pio2_3t = 8.47842766036889956997e-32;  /* the rest */

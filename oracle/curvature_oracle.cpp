@@ -29,8 +29,11 @@ inline float det3(const float m[3][3]) {
 	return m[0][0] * minor_m12_m23 - m[0][1] * minor_m11_m23 + m[0][2] * minor_m11_m22;
 }
 
-// calculations.rs:467-498
-void fast_eigenvalues(const float mat[3][3], float out[3]) {
+// calculations.rs:467-498.  LIBM = false: acos / cos of include/treee_f32_trig.h (shared with the kernels: bit parity);
+// LIBM = true: this host's libm acosf / cosf, i.e. what Rust's f32::acos / f32::cos forward to on a linux-gnu target -- the
+// reference's own last bits on this machine, kept so that the shared definition is measured against the reference and not
+// only against itself (tests: explicit absolute bound).
+template <bool LIBM> void fast_eigenvalues_t(const float mat[3][3], float out[3]) {
 	float p1 = square(mat[0][1]) + square(mat[0][2]) + square(mat[1][2]);
 	if (p1 == 0.0f) { // :473-476 diagonal returned unsorted
 		out[0] = mat[0][0];
@@ -54,17 +57,18 @@ void fast_eigenvalues(const float mat[3][3], float out[3]) {
 	else if (r >= 1.0f)
 		phi = 0.0f;
 	else
-		phi = treee_acos_f32(r) / 3.0f;
-	float eig_1 = q + 2.0f * p * treee_cos_f32(phi);
-	float eig_3 = q + 2.0f * p * treee_cos_f32(phi + (2.0f * PI / 3.0f));
+		phi = (LIBM ? std::acos(r) : treee_acos_f32(r)) / 3.0f;
+	float eig_1 = q + 2.0f * p * (LIBM ? std::cos(phi) : treee_cos_f32(phi));
+	float eig_3 = q + 2.0f * p * (LIBM ? std::cos(phi + (2.0f * PI / 3.0f)) : treee_cos_f32(phi + (2.0f * PI / 3.0f)));
 	float eig_2 = 3.0f * q - eig_1 - eig_3;
 	out[0] = eig_1;
 	out[1] = eig_2;
 	out[2] = eig_3;
 }
+void fast_eigenvalues(const float mat[3][3], float out[3]) { fast_eigenvalues_t<false>(mat, out); }
 
 // calculations.rs:342-368 for one point, neighbours in returned (ascending) order
-float curve_from(const float *xyz, const orc_entry *nb, uint64_t count) {
+template <bool LIBM = false> float curve_from(const float *xyz, const orc_entry *nb, uint64_t count) {
 	float len = (float)count; // neighbors.len() as f32
 	float mean[3] = {0.0f, 0.0f, 0.0f};
 	for (uint64_t j = 0; j < count; ++j) { // :344-346
@@ -86,7 +90,7 @@ float curve_from(const float *xyz, const orc_entry *nb, uint64_t count) {
 	for (int x = 0; x < 3; ++x) // :359-363
 		for (int y = 0; y < 3; ++y) var[x][y] /= len;
 	float eig[3];
-	fast_eigenvalues(var, eig);
+	fast_eigenvalues_t<LIBM>(var, eig);
 	return (3.0f * eig[2]) / (eig[0] + eig[1] + eig[2]); // :368
 }
 
@@ -108,14 +112,19 @@ float orc_curve_from_neighbors(const float *xyz, const orc_entry *nb, uint64_t c
 // the loop body of calculations.rs:342-368 over GIVEN neighbour lists (u32 index[nq][k], the first counts[i] of a row
 // are valid, summed in the order given): separates the arithmetic from the neighbour search when an implementation's
 // lists differ from the KD-tree's inside distance ties
+// libm != 0: acos / cos of this host's libm instead of the shared header (see fast_eigenvalues_t)
 void orc_curve_from_lists(const float *xyz, const uint32_t *index, const uint32_t *counts, uint64_t nq, uint64_t k,
                           float *curve_out, int threads) {
+	orc_curve_from_lists_trig(xyz, index, counts, nq, k, curve_out, threads, 0);
+}
+void orc_curve_from_lists_trig(const float *xyz, const uint32_t *index, const uint32_t *counts, uint64_t nq, uint64_t k,
+                               float *curve_out, int threads, int libm) {
 	auto work = [&](uint64_t lo, uint64_t hi) {
 		std::vector<orc_entry> loc(k);
 		for (uint64_t i = lo; i < hi; ++i) {
 			const uint64_t c = counts ? counts[i] : k;
 			for (uint64_t j = 0; j < c; ++j) loc[j].index = index[i * k + j];
-			curve_out[i] = curve_from(xyz, loc.data(), c);
+			curve_out[i] = libm ? curve_from<true>(xyz, loc.data(), c) : curve_from<false>(xyz, loc.data(), c);
 		}
 	};
 	if (threads <= 1) return work(0, nq);

@@ -75,6 +75,7 @@ def lib():
         L.orc_curve_from_neighbors.argtypes = [vp, vp, u64]
         L.orc_curvature.argtypes = [vp, u64, u64, f32, vp, i32]
         L.orc_curve_from_lists.argtypes = [vp, vp, vp, u64, u64, vp, i32]
+        L.orc_curve_from_lists_trig.argtypes = [vp, vp, vp, u64, u64, vp, i32, i32]
         L.orc_trig_f32.argtypes = [vp, u64, vp, vp, vp, vp]
         L.orc_map_to_u32.restype = u32
         L.orc_map_to_u32.argtypes = [f32]
@@ -186,14 +187,15 @@ def curve_from_neighbors(points, entries):
     return float(lib().orc_curve_from_neighbors(_p(points), _p(entries), len(entries)))
 
 
-def curve_from_lists(points, index, counts=None, threads=1):
-    """calculations.rs:342-368 over given neighbour lists (index [nq, k] u32, first counts[i] valid), summed in list order"""
+def curve_from_lists(points, index, counts=None, threads=1, libm=False):
+    """calculations.rs:342-368 over given neighbour lists (index [nq, k] u32, first counts[i] valid), summed in list order.
+    libm=True: acos / cos of this host's libm (what Rust's f32::acos / cos forward to) instead of the shared header"""
     points = _f32(points, 3)
     index = np.ascontiguousarray(index, dtype=np.uint32)
     nq, k = index.shape
     cnt = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint32)
     out = np.zeros(nq, np.float32)
-    lib().orc_curve_from_lists(_p(points), _p(index), None if cnt is None else _p(cnt), nq, k, _p(out), threads)
+    lib().orc_curve_from_lists_trig(_p(points), _p(index), None if cnt is None else _p(cnt), nq, k, _p(out), threads, 1 if libm else 0)
     return out
 
 

@@ -67,6 +67,10 @@ float orc_curve_from_neighbors(const float *xyz, const orc_entry *nb, uint64_t c
 /* the same for nq given lists (u32 index[nq][k], counts[nq] or NULL = k), summed in the order given */
 void orc_curve_from_lists(const float *xyz, const uint32_t *index, const uint32_t *counts, uint64_t nq, uint64_t k,
                           float *curve_out, int threads);
+// the same with acos / cos of this host's libm (libm != 0) instead of include/treee_f32_trig.h: what a Rust build of the
+// reference on this machine computes (f32::acos / f32::cos forward to acosf / cosf)
+void orc_curve_from_lists_trig(const float *xyz, const uint32_t *index, const uint32_t *counts, uint64_t nq, uint64_t k,
+                               float *curve_out, int threads, int libm);
 /* include/treee_f32_trig.h (the shared acos / cos) beside this host's libm */
 void orc_trig_f32(const float *x, uint64_t n, float *acos_out, float *cos_out, float *libm_acos_out, float *libm_cos_out);
 /* full loop: tree over xyz[n], k neighbours (k=31 in the reference), radius */

@@ -113,3 +113,28 @@ def test_errors_and_empty_input():
     # a lone point: its seed triangle (area 0.005) is below max_distance^2 / 4 and is filtered (segmenting.rs:472-475):
     # no tree, no cell, DELETED_INDEX
     assert one.tolist() == [0] and S == 1
+
+
+def test_nan_points_and_clipped_away_cells_follow_the_reference_rule():
+    """ADVICE r3: a point whose x or z is NaN fails every comparison, so `Tree::contains` (segmenting.rs:331-349) holds for
+    EVERY cell -- also for one clipped to nothing (`from_points` of no vertices, :272-278: min = MAX, max = MIN, no edge to
+    fail) -- and `position()` (:195-197) takes the first cell of the move-to-front order.  That is the reference's rule, and
+    the library keeps it (the advisor's "skip empty cells" would change results): ids identical to the restatement on a
+    cloud with NaN points in several slices and with coincident sites (centroids handed down onto the same spot)."""
+    import treee_amd as T
+    from oracle import segmenting_restatement as R
+
+    rng = np.random.default_rng(21)
+    pts, _ = _cloud(rng, [(-4.0, -4.0), (4.0, -3.0), (0.0, 5.0)], 700, height=5.0)
+    twin, _ = _cloud(np.random.default_rng(21), [(-4.0, -4.0)], 700, height=5.0)  # the first column again: coincident hull areas
+    pts = np.concatenate([pts, twin[:700]])
+    nan_rows = rng.choice(len(pts), 25, replace=False)
+    bmin, bmax = _bbox(pts)  # (the box of the finite cloud: the reference takes it from the LAS header, not from the points)
+    pts[nan_rows[:10], 0] = np.nan
+    pts[nan_rows[10:20], 2] = np.nan
+    pts[nan_rows[20:], 0] = np.nan
+    pts[nan_rows[20:], 2] = np.nan
+    for seed in (0, 5):
+        seg, S = T.segment_slices(pts, bbox_min=(bmin[0], 0.0, bmin[1]), bbox_max=(bmax[0], 0.0, bmax[1]), max_distance=0.75, seed=seed)
+        want, S2 = R.segment_slices(pts, bmin, bmax, 0.75, seed)
+        assert S == S2 and np.array_equal(seg, want)

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <numeric>
 #include <string>
+#include <system_error>
 #include <thread>
 
 using namespace treee;
@@ -101,16 +102,25 @@ struct DeviceRun { // a context on a private stream, destroyed with the frame
 template <class F> int32_t run_on_devices(const int32_t *devices, uint32_t n_dev, F &&body) {
 	std::vector<int32_t> rc(n_dev, TREEE_OK);
 	std::vector<std::string> msg(n_dev);
+	auto run = [&](uint32_t d) {
+		try {
+			rc[d] = body(d, devices[d]);
+		} catch (const std::exception &e) {
+			rc[d] = set_err(TREEE_ERR_NOMEM, "device %d: %s", devices[d], e.what());
+		}
+		if (rc[d] != TREEE_OK) msg[d] = treee_last_error(); // (the message is thread-local: carry it to the caller's thread)
+	};
 	std::vector<std::thread> pool;
-	for (uint32_t d = 0; d < n_dev; ++d)
-		pool.emplace_back([&, d] {
-			try {
-				rc[d] = body(d, devices[d]);
-			} catch (const std::exception &e) {
-				rc[d] = set_err(TREEE_ERR_NOMEM, "device %d: %s", devices[d], e.what());
-			}
-			if (rc[d] != TREEE_OK) msg[d] = treee_last_error(); // (the message is thread-local: carry it to the caller's thread)
-		});
+	pool.reserve(n_dev); // (emplace_back below never reallocates: a failure can only come from the thread itself)
+	for (uint32_t d = 0; d < n_dev; ++d) {
+		try {
+			pool.emplace_back(run, d);
+		} catch (const std::system_error &) {
+			// no more threads: this device's share runs on the calling thread -- nothing may unwind through joinable
+			// threads (std::terminate) or across the C ABI
+			run(d);
+		}
+	}
 	for (auto &t : pool) t.join();
 	for (uint32_t d = 0; d < n_dev; ++d)
 		if (rc[d] != TREEE_OK) return set_err(rc[d], "device %d (list position %u): %s", devices[d], d, msg[d].c_str());
@@ -156,9 +166,9 @@ int32_t treee_curvature_segments_multi(const int32_t *devices, uint32_t n_device
 			TREEE_TRY(d_curve.alloc(m));
 			TREEE_HIP(hipMemcpyAsync(d_xyz.p, sh.xyz.data(), m * 12, hipMemcpyHostToDevice, run.stream));
 			TREEE_HIP(hipMemcpyAsync(d_seg.p, sh.seg.data(), m * 4, hipMemcpyHostToDevice, run.stream));
+			std::vector<float> h(m); // (before the handle exists: an allocation failure here has nothing to leak)
 			treee_knn *t = nullptr;
 			TREEE_TRY(knn_build_segments_cube(run.ctx, d_xyz.p, d_seg.p, m, (uint32_t)sh.seg_ids.size(), cube, &t));
-			std::vector<float> h(m);
 			int32_t rc = treee_curvature_dev(run.ctx, t, k, max_dist_sq, d_curve.p);
 			if (rc == TREEE_OK) {
 				hipError_t e = hipMemcpyAsync(h.data(), d_curve.p, m * 4, hipMemcpyDeviceToHost, run.stream);

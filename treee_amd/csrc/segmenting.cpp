@@ -618,7 +618,9 @@ int32_t segment_slices(const float *xyz, uint64_t n, const float *bbox_min_xz, c
 						else
 							extra[ci].push_back({(uint32_t)k, c});
 					}
-				} else { // NaN compares false everywhere: `contains` holds for every non-empty cell
+				} else { // NaN compares false everywhere: `contains` holds for EVERY cell -- a cell clipped to nothing included, as
+					// in the reference (from_points of no vertices, segmenting.rs:272-278: no bound and no edge can fail, and
+					// position() at :195-197 takes the first of the move-to-front order); tests/test_segmenting.py pins it
 					for (size_t c = 0; c < as.trees.size(); ++c) {
 						if (!as.trees[c].contains(q, 0.1f)) continue;
 						if (as.first[k] == NONE32)

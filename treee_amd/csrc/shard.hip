@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void k_select_write(const float *__restrict__ 
 
 
 // header row of every sender's block: the count it wanted to send (int32 bits in .x)
-__global__ void k_block_heads(const float *__restrict__ recv, uint32_t world, uint64_t block_floats, uint32_t *__restrict__ heads) {
-	const uint32_t r = threadIdx.x;
+__global__ __launch_bounds__(256) void k_block_heads(const float *__restrict__ recv, uint32_t world, uint64_t block_floats, uint32_t *__restrict__ heads) {
+	const uint32_t r = blockIdx.x * 256u + threadIdx.x;
 	if (r < world) heads[r] = __float_as_uint(recv[(uint64_t)r * block_floats]);
 }
 __global__ void k_set_head(float *__restrict__ send, const uint32_t *__restrict__ count) { send[0] = __uint_as_float(*count); }
@@ -137,6 +137,10 @@ int32_t treee_shard_exchange_ghosts_dev(treee_ctx *ctx, treee_comm *comm, float 
 	*n_ghost_out = *most_sent_out = 0;
 	const int world = comm->world, rank = comm->rank;
 	if (world == 1) return TREEE_OK;
+	// the ghost selection runs over the world's blocks in ONE pass whose positions are 32-bit: refuse what cannot fit before
+	// anything is allocated for it
+	if ((send_cap + 1) >= (1ull << 32) / (uint64_t)world)
+		return set_err(TREEE_ERR_UNSUPPORTED, "treee_shard_exchange_ghosts_dev: (send_cap + 1) x world = %llu x %d rows exceed 2^32", (unsigned long long)(send_cap + 1), world);
 	const float x0 = tile_box[0], x1 = tile_box[1], z0 = tile_box[2], z1 = tile_box[3], inf = INFINITY;
 	const uint64_t block = (send_cap + 1) * 3; // floats per rank: header row + send_cap points
 	float *d_send = nullptr, *d_recv = nullptr;
@@ -155,7 +159,7 @@ int32_t treee_shard_exchange_ghosts_dev(treee_ctx *ctx, treee_comm *comm, float 
 	hipLaunchKernelGGL(k_set_head, dim3(1), dim3(1), 0, st, d_send, d_cnt);
 	TREEE_LAUNCH_CHECK();
 	TREEE_TRY(comm->all_gather_dev(ctx, d_send, d_recv, block * 4));
-	hipLaunchKernelGGL(k_block_heads, dim3(1), dim3(world < 64 ? 64 : ((world + 63) / 64) * 64), 0, st, d_recv, (uint32_t)world, block, d_heads);
+	hipLaunchKernelGGL(k_block_heads, dim3(div_up((uint64_t)world, 256)), dim3(256), 0, st, d_recv, (uint32_t)world, block, d_heads);
 	TREEE_LAUNCH_CHECK();
 	TREEE_HIP(hipMemsetAsync(d_recv + (uint64_t)rank * block, 0xFF, block * 4, st)); // own block: not a ghost of oneself
 	const Box2 dilated = {x0 - halo, x1 + halo, z0 - halo, z1 + halo}, none = {0.0f, 0.0f, 0.0f, 0.0f};
