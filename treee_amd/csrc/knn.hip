@@ -521,17 +521,39 @@ constexpr int FRONT_CAP = TREEE_FRONT_CAP; // BFS frontier; the default aliases 
 // SEG: the cloud is segmented (build_segmented) -- records are padded with (NaN, NaN, NaN, ~0u) so that no bucket
 // straddles a segment, tree nodes carry the range of segments below them, and a query only descends into / scans
 // nodes and buckets of its own segment: the result is what one KD-tree per segment returns (calculations.rs:329).
-template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SKT <= 32 ? TREEE_KNN_WAVES : 2) void k_knn_sorted32(KnnArgs a) {
+struct KnnLds {
+	float tile[3][BUCKET];                // SoA candidate tile (x[], y[], z[])
+	uint32_t buf[2 * SBUF * 64];          // [pos | distance bits][slot][lane]: conflict-free per slot
+	uint32_t s_list[LIST_CAP];            // candidate buckets of the wave
+	float4 s_gbox[TREEE_GROUP][2];        // boxes of the current group of listed buckets
+};
+__device__ __forceinline__ KnnLds &knn_lds() {
+	__shared__ __attribute__((aligned(16))) KnnLds s;
+	return s;
+}
+typedef const __attribute__((address_space(4))) struct KnnArgs *KnnArgsInKernarg; // the kernel's own argument block
+template <bool SEG, int SKT> __device__ __attribute__((noinline)) void knn_wave_overflowed(KnnArgsInKernarg ka, uint32_t wave_id);
+
+// OVF = false: the kernel proper.  A wave whose candidate list overflows (a huge search radius: 195 of 234 375 waves of the
+// 15 M-point forest) starts over as OVF = true -- the same prologue, then a packet traversal of the tree instead of the list --
+// through a REAL call (knn_wave_overflowed, noinline).  Inlined (rounds 1-3) the traversal was a third copy of the scan and
+// merge code whose register assignment the allocator reconciled with the other two through scratch memory at every phase
+// transition: 220 B / lane of spills, 3.5 GB of HBM writes per 15 M-point launch for 60 MB of output.  Behind a call its
+// registers are its own affair: the kernel proper needs no scratch, and the call costs the 195 waves that make it a second
+// prologue.  (As a second launch behind the kernel the overflowed waves -- ~4 ms each -- formed a tail of 7 ms: they have to
+// start early, among the others, which the dispatch table arranges.)
+template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ void knn_wave(const KnnArgs &a, const uint32_t wave_id) {
 	constexpr int SK = SKT; // list length of this instantiation: 32 (k <= 32) or 16 (k <= 16: half the list registers and merge work, no spills)
-	__shared__ __attribute__((aligned(16))) float tile[3][BUCKET]; // SoA candidate tile (x[], y[], z[])
-	__shared__ uint32_t buf[2 * SBUF * 64]; // [pos | distance bits][slot][lane]: conflict-free per slot
-	__shared__ uint32_t s_list[LIST_CAP];
+	KnnLds &lds = knn_lds(); // one block of LDS whichever instantiation runs (OVF = true is called from OVF = false)
+	auto &tile = lds.tile;
+	auto &buf = lds.buf;
+	auto &s_list = lds.s_list;
 	constexpr uint32_t GROUP = TREEE_GROUP; // listed buckets whose boxes are in LDS at a time
-	__shared__ __attribute__((aligned(16))) float4 s_gbox[GROUP][2]; // boxes of the current group of listed buckets
+	auto &s_gbox = lds.s_gbox;
 	// LDS is handed out in units of 1 280 bytes (160 KB / 128): 12 workgroups per CU -- the 3 waves per SIMD the registers
 	// allow -- fit only if each takes at most 10 units.  With 13 056 bytes (GROUP = 64) a CU held 11: measured 8.78 instead
 	// of 8.27 ms (12 800 and 12 928 bytes differ by exactly that step).
-	static_assert(SKT > 32 || TREEE_FRONT_CAP > TREEE_SBUF * 64 || sizeof(tile) + sizeof(buf) + sizeof(s_list) + sizeof(s_gbox) <= 10 * 1280,
+	static_assert(SKT > 32 || TREEE_FRONT_CAP > TREEE_SBUF * 64 || sizeof(KnnLds) <= 10 * 1280,
 	              "the workgroup's LDS must stay within 10 allocation units of 1 280 bytes (12 workgroups per CU)");
 	const int lane = threadIdx.x;
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -541,7 +563,6 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 	// near the end of the kernel
 	// and the workgroups that share an XCD (blockIdx % 8) walk the same Morton ranges, so its L2 serves the
 	// bucket re-reads of neighbouring waves (build_bvh lays the table out that way; ~0u = padding)
-	const uint32_t wave_id = (!a.q_xyz && a.wave_order) ? a.wave_order[blockIdx.x] : blockIdx.x;
 	if (wave_id == ~0u) return;
 	const uint32_t slot = wave_id * 64u + lane;
 	bool live = slot < a.nq;
@@ -554,7 +575,7 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 			qy = a.q_xyz[3ull * row + 1];
 			qz = a.q_xyz[3ull * row + 2];
 		}
-		start = a.q_start[blockIdx.x];
+		start = a.q_start[wave_id];
 	} else {
 		if (live) {
 			const float4 p = a.pts[slot];
@@ -757,6 +778,8 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 	// live in the (idle) tile memory.
 	constexpr int NG = TREEE_NG, GL = 64 / NG; // sub-boxes per wave, lanes per sub-box
 	float *gbox = &tile[0][0]; // [NG][8]: lo.xyz, tau bits, hi.xyz, pad
+	uint32_t list_m = 0;
+	if constexpr (!OVF) {
 	{
 		const float q[3] = {qx, qy, qz};
 		float glo[3], ghi[3];
@@ -795,7 +818,7 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 #else
 	uint32_t *front = (uint32_t *)buf; // two frontiers of FRONT_CAP nodes alias the (empty) buffer
 #endif
-	uint32_t cur = 0, m = 0, list_m = 0;
+	uint32_t cur = 0, m = 0;
 	for (uint32_t nd = a.P + start; nd > 1u; nd >>= 1) ++m; // tree depth = number of seeds (<= 31)
 	if ((uint32_t)lane < m) front[lane] = ((a.P + start) >> lane) ^ 1u;
 	__syncthreads();
@@ -859,10 +882,19 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 		__syncthreads();
 	}
 	__syncthreads();
+	if (overflow) { // wave-uniform; nothing has been written for this wave yet
+		if (DIAG && a.stats && lane == 0) atomicAdd(&a.stats[8], 1u);
+		// (one callee per list length class: a longer list keeps the same first k.  The callee reads the arguments from the
+		// kernel's argument block -- KnnArgs is the kernel's only parameter --: handed over by value they were parked on the
+		// stack at kernel entry by every wave, 2 KB of scratch writes each)
+		knn_wave_overflowed<SEG, (SKT <= 32 ? 32 : 64)>((KnnArgsInKernarg)__builtin_amdgcn_kernarg_segment_ptr(), wave_id);
+		return;
+	}
+	} // !OVF
 
 	PH(1);
 	ST(st_ph[7] = list_m);
-	if (!overflow) {
+	if constexpr (!OVF) {
 		// ---- scan the listed buckets; the next bucket's load is in flight during each scan -------
 		for (uint32_t g = 0; g < list_m; g += GROUP) {
 			const uint32_t gcount = (list_m - g) < GROUP ? (list_m - g) : GROUP;
@@ -972,7 +1004,7 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 			}
 		}
 	} else {
-		// ---- fallback (huge search radius): packet traversal, bottom-up from the own bucket -------
+		// ---- the waves whose list overflowed (huge search radius): packet traversal, bottom-up from the own bucket -------
 		uint32_t node = a.P + start;
 		while (node > 1u) {
 			const uint32_t root = node ^ 1u;
@@ -1009,7 +1041,6 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 		const uint32_t cyc = (uint32_t)((__builtin_amdgcn_s_memtime() - st_t0) >> 6); // 64-cycle units
 		atomicAdd(&a.stats[6], cyc >> 4);
 		atomicMax(&a.stats[7], cyc);
-		if (overflow) atomicAdd(&a.stats[8], 1u);
 		for (int i = 0; i < 7; ++i) atomicAdd(&a.stats[40 + i], st_ph[i] >> 10);
 		atomicAdd(&a.stats[50], st_ph[8] >> 10);
 		atomicAdd(&a.stats[47], st_ph[7]);
@@ -1069,6 +1100,15 @@ template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SK
 		fast_eigenvalues(var, eig);
 		a.out_curve[row] = (3.0f * eig[2]) / (eig[0] + eig[1] + eig[2]);
 	}
+}
+
+template <bool DIAG, bool SEG, int SKT = 32> __global__ __launch_bounds__(64, SKT <= 32 ? TREEE_KNN_WAVES : 2) void k_knn_sorted32(KnnArgs a) {
+	knn_wave<DIAG, SEG, SKT, false>(a, (!a.q_xyz && a.wave_order) ? a.wave_order[blockIdx.x] : blockIdx.x);
+}
+template <bool SEG, int SKT> __device__ __attribute__((noinline)) void knn_wave_overflowed(KnnArgsInKernarg ka, uint32_t wave_id) {
+	__syncthreads(); // the prologue below reuses the LDS the caller's BFS was reading
+	const KnnArgs a = *(const KnnArgs *)ka;
+	knn_wave<false, SEG, SKT, true>(a, wave_id);
 }
 
 // start bucket of each query wave: the bucket holding the first query's key (the order of the tree: Hilbert, or Morton with TREEE_KNN_MORTON)
