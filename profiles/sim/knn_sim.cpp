@@ -89,7 +89,7 @@ struct Counters {
 	       tq = 0 /* transposed (query, bucket) pairs */, tq_pass = 0, boxtests = 0 /* per-lane box tests, wave instructions groups */, bfs_batches = 0,
 	       listed = 0, rounds = 0, evals_useful = 0, subtests = 0, lanes_need_sum = 0, full_scans = 0, small_scans = 0, idle_lane_steps = 0, retests = 0,
 	       max_lane_appended = 0, fill_hist[17] = {}, flush_phase[4] = {}, lanes_over8_at_flush = 0, sum_final_thr_ratio = 0,
-	       q_total = 0, q_zero = 0, q_low = 0, q_need_sum = 0, h_total = 0, h_zero = 0;
+	       q_total = 0, q_zero = 0, q_low = 0, q_need_sum = 0, h_total = 0, h_zero = 0, flush_ce = 0, flush_wide = 0, flush_lo_untouched = 0, flush_lo8_untouched = 0, lanes_lo_touched = 0;
 	void add(const Counters &o) {
 		double *a = &waves;
 		const double *b = &o.waves;
@@ -115,18 +115,52 @@ struct Wave {
 			buf[l].reserve(SBUF);
 		}
 	}
+	int pair_xor = 0; // > 0: lanes l and l ^ pair_xor share 2 x SBUF slots
+	int sbuf = SBUF;
 	bool any_pending(size_t more_than) const {
+		if (more_than == 0 || pair_xor == 0) {
+			const size_t lim = more_than == 0 ? 0 : (size_t)sbuf - 4;
+			for (int l = 0; l < 64; ++l)
+				if (buf[l].size() > lim) return true;
+			return false;
+		}
 		for (int l = 0; l < 64; ++l)
-			if (buf[l].size() > more_than) return true;
+			if (buf[l].size() + buf[l ^ pair_xor].size() > (size_t)(2 * sbuf - 8)) return true;
 		return false;
 	}
 	void flush() {
 		k.flush_phase[phase] += 1;
+		{
+			size_t mx = 0;
+			for (int l = 0; l < 64; ++l) mx = std::max(mx, buf[l].size());
+			// compare-exchanges of the merge: 16 entries per lane 60 + 16 + 80; up to 32: 191 + 32 + 80; beyond: one more 16-pass each
+			k.flush_ce += mx <= 16 ? 156 : (mx <= 32 ? 303 : 303 + 156 * (double)((mx - 32 + 15) / 16));
+			k.flush_wide += mx > 16;
+		}
+		{
+			bool lo_touched = false, lo8_touched = false;
+			for (int l = 0; l < 64; ++l)
+				for (uint64_t e : buf[l]) {
+					if (e < L[l][15]) {
+						lo_touched = true;
+						k.lanes_lo_touched += 1;
+						break;
+					}
+				}
+			for (int l = 0; l < 64 && !lo8_touched; ++l)
+				for (uint64_t e : buf[l])
+					if (e < L[l][7]) {
+						lo8_touched = true;
+						break;
+					}
+			k.flush_lo_untouched += !lo_touched;
+			k.flush_lo8_untouched += !lo8_touched;
+		}
 		for (int l = 0; l < 64; ++l) {
 			k.fill_hist[std::min<size_t>(16, buf[l].size())] += 1;
 			if (buf[l].size() > 8) k.lanes_over8_at_flush += 1;
 			if (!buf[l].empty()) {
-				uint64_t tmp[SK + SBUF];
+				uint64_t tmp[SK + 4 * SBUF];
 				memcpy(tmp, L[l], sizeof(uint64_t) * SK);
 				memcpy(tmp + SK, buf[l].data(), sizeof(uint64_t) * buf[l].size());
 				const size_t m = SK + buf[l].size();
@@ -281,7 +315,7 @@ struct Wave {
 					}
 					if (!np) continue;
 					k.tq_pass += 1;
-					if ((size_t)np > SBUF - buf[l].size()) {
+					if ((size_t)np > (pair_xor ? 2 * sbuf - buf[l].size() - buf[l ^ pair_xor].size() : sbuf - buf[l].size())) {
 						full |= 1ull << l;
 						continue;
 					}
@@ -417,9 +451,16 @@ int main(int argc, char **argv) {
 	struct Variant {
 		std::string name;
 		int kind, SUB, C, nbr_pre, nbr_total, lazy, tb;
+		int pair_xor = 0, sbuf = SBUF;
 	};
 	std::vector<Variant> vs = {
 	    {"cur nbr4 tb20", 0, 0, 0, 4, 4, 0, 20},
+	    {"cur pair l^32", 0, 0, 0, 4, 4, 0, 20, 32, 16},
+	    {"cur pair l^1", 0, 0, 0, 4, 4, 0, 20, 1, 16},
+	    {"cur pair l^16", 0, 0, 0, 4, 4, 0, 20, 16, 16},
+	    {"cur sbuf 24", 0, 0, 0, 4, 4, 0, 20, 0, 24},
+	    {"cur sbuf 32", 0, 0, 0, 4, 4, 0, 20, 0, 32},
+	    {"cur sbuf 64", 0, 0, 0, 4, 4, 0, 20, 0, 64},
 	    {"pl sub64 C=all nbr4", 1, 64, 100000, 4, 4, 0, 0},
 	    {"pl sub32 C=all nbr4", 1, 32, 100000, 4, 4, 0, 0},
 	    {"pl sub16 C=all nbr4", 1, 16, 100000, 4, 4, 0, 0},
@@ -441,6 +482,8 @@ int main(int argc, char **argv) {
 #pragma omp for schedule(dynamic, 16)
 			for (uint32_t b = 2; b < c.nb - 3; b += stride) {
 				Wave w(c, k, b);
+				w.pair_xor = v.pair_xor;
+				w.sbuf = v.sbuf;
 				if (v.kind == 0)
 					w.run_current(v.nbr_total, v.tb);
 				else
@@ -465,7 +508,8 @@ int main(int argc, char **argv) {
 		printf("%-30s %7.2f %7.2f %7.1f %7.2f %7.1f %7.1f %7.1f %7.1f %7.2f %7.2f %7.1f | %8.0f\n", v.name.c_str(), total.buckets / W, total.listed / W, total.steps / W,
 		       total.flushes / W, total.appended / W / 64.0, total.tq / W, total.boxtests / W, total.subtests / W, total.rounds / W, total.retests / W,
 		       total.steps > 0 ? 100.0 * total.idle_lane_steps / (total.steps * 64.0) : 0.0, valu);
-		if (v.kind == 0) {
+		if (v.kind == 0) printf("   flush compare-exchanges per wave %.0f (wide flushes %.2f) | flushes in which no lane gets an entry below its 16th: %.2f, below its 8th: %.2f; lanes per flush with one below the 16th %.1f\n", total.flush_ce / W, total.flush_wide / W, total.flush_lo_untouched / W, total.flush_lo8_untouched / W, total.lanes_lo_touched / total.flushes);
+		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF) {
 			printf("   max-lane appended per wave %.1f | flushes by phase own %.2f nbr %.2f list %.2f | lanes with > 8 pending at a flush %.2f | fill histogram:", total.max_lane_appended / W,
 			       total.flush_phase[0] / W, total.flush_phase[1] / W, total.flush_phase[2] / W, total.lanes_over8_at_flush / total.flushes);
 			for (int i = 0; i <= 16; ++i) printf(" %.1f%%", 100.0 * total.fill_hist[i] / (total.flushes * 64));

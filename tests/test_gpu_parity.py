@@ -201,7 +201,11 @@ def test_knn_structure_from_an_octree_orders_cells_like_the_point_sort(T):
     dup = np.concatenate([forest[:50_000], forest[:50_000], forest[:10_000]])
     uniform = quantised_cloud(100_000, 17, extent=(2000, 2000, 2000))
     lattice = (np.random.default_rng(3).integers(0, 12, (63, 3)) * 0.25).astype(np.float32)  # 63 points, many equal distances: small clouds too
-    for name, pts in (("forest", forest), ("duplicates", dup), ("uniform", uniform), ("lattice", lattice)):
+    # >= 1 M points, most cells holding one point, no 2^-7 block near 512 points: the structure behind an octree takes its
+    # Hilbert order from tiles of whole blocks sorted in LDS (hilbert_order_by_blocks, round 4) -- the benchmark cloud's path
+    big, _ = synth.forest_cloud(1_300_000, plot=200.0 * (1.3 / 15.0) ** 0.5)
+    big_dup = np.concatenate([big[:1_100_000], big[:150_000], big[400_000:450_000]])
+    for name, pts in (("forest", forest), ("duplicates", dup), ("uniform", uniform), ("lattice", lattice), ("blocks", big), ("blocks_duplicates", big_dup)):
         d_pts = torch.from_numpy(pts).cuda()
         oc = T.Octree(d_pts)
         a = T.KDTree.from_octree(oc)

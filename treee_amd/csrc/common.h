@@ -303,6 +303,7 @@ struct SortedCloud {
 	int device = 0;
 	bool hilbert = false; // d_keys are Hilbert indices (the kNN structure's private copy), not Morton keys
 	int crowded = -1; // some Morton cell holds more than LONG_RUN points: -1 unknown, else 0 / 1 (long_run_flag_dev)
+	int block7_big = -1; // some 2^-7 block may hold BLOCK7_MAX points or more: -1 unknown, else 0 / 1 (the same flag word, bit 1)
 	float cell_share = -1.0f; // occupied 2^-10 cells per point, estimated from a sample of the sorted keys: < 0 unknown (distinct_keys_dev; asked in the build's own round trip)
 	float *d_cube = nullptr;   // (corner.xyz, size) on the device when the cube was computed from the data
 	bool cube_pending = false; // corner / size above are not yet valid on the host (cube_fetch_async + cube_commit)
@@ -325,6 +326,8 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 #endif
 constexpr uint32_t LONG_RUN = TREEE_LONG_RUN;
 int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_sorted_keys, uint64_t n, uint32_t *d_flag);
+// (bit 1 of that flag: some 2^-7 block -- keys sharing their top 21 bits -- may hold BLOCK7_MAX points or more)
+constexpr uint32_t BLOCK7_MAX = 2048, BLOCK7_PROBE = BLOCK7_MAX - 64;
 // d_out[0] / d_out[1] (device) = distinct values / keys in a sample of windows of the sorted keys
 int32_t distinct_keys_dev(treee_ctx *ctx, const uint32_t *d_sorted_keys, uint64_t n, uint32_t *d_out);
 // The cube of a cloud built from its data stays on the device (keys are generated from there); the host copy is

@@ -22,6 +22,7 @@
 #include "../../include/treee_f32_trig.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 using namespace treee;
 
@@ -1066,31 +1067,75 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		}
 	}
 	if (a.out_curve) { // treee/src/calculations.rs:342-368, neighbours in ascending order
+		// The neighbours' coordinates are gathered ONCE and kept in registers (the list is dead from here on: 3 x SK values);
+		// a slot beyond the lane's count holds position 0 -- a valid address -- and is left out of the sums below.  Nearly
+		// every wave has count == k in all its lanes (unbounded radius): then no sum carries a per-lane condition.
 		const float len = (float)count;
 		float mean[3] = {0.0f, 0.0f, 0.0f};
+		float var[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+		if constexpr (SKT > 32) { // (64 x 3 coordinates do not fit beside the list: two gathers)
+#pragma unroll
+			for (int s = 0; s < SK; ++s) {
+				if ((uint32_t)s < count) {
+					const float4 p = a.pts[key_pos(L[s])];
+					mean[0] += p.x;
+					mean[1] += p.y;
+					mean[2] += p.z;
+				}
+			}
+			mean[0] = mean[0] / len;
+			mean[1] = mean[1] / len;
+			mean[2] = mean[2] / len;
+#pragma unroll
+			for (int s = 0; s < SK; ++s) {
+				if ((uint32_t)s < count) {
+					const float4 p = a.pts[key_pos(L[s])];
+					const float df[3] = {p.x - mean[0], p.y - mean[1], p.z - mean[2]};
+#pragma unroll
+					for (int x = 0; x < 3; ++x)
+#pragma unroll
+						for (int y = 0; y < 3; ++y) var[x][y] += df[x] * df[y];
+				}
+			}
+		} else {
+		float nx[SK], ny[SK], nz[SK];
 #pragma unroll
 		for (int s = 0; s < SK; ++s) {
-			if ((uint32_t)s < count) {
+			if ((uint32_t)s < k) { // (wave-uniform)
 				const float4 p = a.pts[key_pos(L[s])];
-				mean[0] += p.x;
-				mean[1] += p.y;
-				mean[2] += p.z;
+				nx[s] = p.x;
+				ny[s] = p.y;
+				nz[s] = p.z;
 			}
 		}
-		mean[0] = mean[0] / len;
-		mean[1] = mean[1] / len;
-		mean[2] = mean[2] / len;
-		float var[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+		const bool all_full = __all(count == k);
+		auto sums = [&](auto full) __attribute__((always_inline)) {
 #pragma unroll
-		for (int s = 0; s < SK; ++s) {
-			if ((uint32_t)s < count) {
-				const float4 p = a.pts[key_pos(L[s])];
-				const float df[3] = {p.x - mean[0], p.y - mean[1], p.z - mean[2]};
-#pragma unroll
-				for (int x = 0; x < 3; ++x)
-#pragma unroll
-					for (int y = 0; y < 3; ++y) var[x][y] += df[x] * df[y];
+			for (int s = 0; s < SK; ++s) {
+				if ((uint32_t)s < k && (decltype(full)::value || (uint32_t)s < count)) {
+					mean[0] += nx[s];
+					mean[1] += ny[s];
+					mean[2] += nz[s];
+				}
 			}
+			mean[0] = mean[0] / len;
+			mean[1] = mean[1] / len;
+			mean[2] = mean[2] / len;
+#pragma unroll
+			for (int s = 0; s < SK; ++s) {
+				if ((uint32_t)s < k && (decltype(full)::value || (uint32_t)s < count)) {
+					const float df[3] = {nx[s] - mean[0], ny[s] - mean[1], nz[s] - mean[2]};
+#pragma unroll
+					for (int x = 0; x < 3; ++x)
+#pragma unroll
+						for (int y = 0; y < 3; ++y) var[x][y] += df[x] * df[y];
+				}
+			}
+		};
+		if (all_full)
+			sums(std::true_type{});
+		else
+			sums(std::false_type{});
 		}
 #pragma unroll
 		for (int x = 0; x < 3; ++x)
@@ -1478,6 +1523,230 @@ int32_t hilbert_order_by_cells(treee_ctx *ctx, const SortedCloud *sc, SortedClou
 	return TREEE_OK;
 }
 
+// ---- Hilbert order of a Morton-sorted cloud by sorting TILES OF WHOLE BLOCKS in LDS (round 4) -----------------------------------
+// The Hilbert curve and the Z curve visit the same octants at every level, only in another child order: the first 3 j bits of
+// a point's Hilbert index are a function of the first 3 j bits of its Morton key.  So the points of one 2^-7 block (keys
+// sharing their top 21 bits) are contiguous in BOTH orders, and re-sorting a Morton-sorted cloud by Hilbert index is
+//   (1) a permutation of the blocks -- where block m starts in the Hilbert order is the number of points in the blocks with a
+//       smaller 21-bit Hilbert prefix: a scan over a dense table of 2^21 block sizes, read in Hilbert order --, and
+//   (2) inside every block a stable sort by the low 9 bits of the Hilbert index (three levels).
+// A workgroup takes the whole blocks that start inside its tile of BLK_TILE positions (blocks hold fewer than BLOCK7_MAX points
+// -- the build's existing round trip asked, bit 1 of long_run_flag_dev --, so at most BLK_CAP), sorts the composite keys
+// (block offset in the tile, low Hilbert bits, position in the tile) -- all distinct -- with a bitonic network in LDS and
+// writes keys, permutation and records to block start + rank.  Bytes per point: 4 (key) + 16 (record) read, 24 written, against
+// 8 (Hilbert conversion) + 4 x 16 + 4 (four radix passes and their histograms) + 16 + 24 (record gather) of the point sort
+// it replaces; same arrays, bit for bit (test_knn_structure_from_an_octree_orders_cells_like_the_point_sort).  15 M points /
+// 200 m: structure stage 1.58 -> see profiles/README.md.  Clouds with a fuller block keep the other paths.
+constexpr uint32_t BLK_BITS = 21, BLK_CELLS = 1u << BLK_BITS, BLK_TILE = 1536, BLK_CAP = 2048, BLK_CAP_BIG = 4096;
+// (tiles whose blocks do not fit BLK_CAP -- a block of more than 512 points at their edge: 25 of 157 000 blocks of the 15 M-point
+// forest -- are listed and sorted by a second launch with twice the LDS; a block of BLOCK7_MAX points fits neither)
+static_assert(BLK_TILE + BLOCK7_MAX <= BLK_CAP_BIG && BLOCK7_MAX <= 2048, "a tile's whole blocks must fit the larger LDS sort, a position in a block 11 bits");
+
+// start7[m] / end7[m]: the sorted positions [start, end) of the points whose key >> 9 == m (both tables zeroed before)
+__global__ __launch_bounds__(256) void k_block_bounds(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ start7, uint32_t *__restrict__ end7) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t m = keys[i] >> 9;
+	if (i == 0 || (keys[i - 1] >> 9) != m) start7[m] = i;
+	if (i + 1 == n || (keys[i + 1] >> 9) != m) end7[m] = i + 1u;
+}
+// block sizes in the order of the blocks' 21-bit Hilbert prefixes
+__global__ __launch_bounds__(256) void k_block_sizes_hilbert(const uint32_t *__restrict__ start7, const uint32_t *__restrict__ end7, uint32_t *__restrict__ size_h) {
+	__shared__ uint16_t s_lut[24 * 8];
+	if (threadIdx.x < 24 * 8) {
+		constexpr uint16_t LUT[24 * 8] = {TREEE_HILBERT_LUT_INIT};
+		s_lut[threadIdx.x] = LUT[threadIdx.x];
+	}
+	__syncthreads();
+	const uint32_t m = blockIdx.x * 256u + threadIdx.x; // (the grid covers the table exactly)
+	size_h[hilbert_of_morton_lut(m << 9, s_lut) >> 9] = end7[m] - start7[m];
+}
+// v <- min or max of (v, the value lane ^ S holds), S < 64: a VALU exchange (DPP within a row of 16 lanes, the gfx950 row /
+// half swaps beyond) -- through ds_bpermute the same network was bound by the LDS pipe (428 us per 15 M points)
+template <uint32_t S> __device__ __forceinline__ uint32_t lane_xor_minmax(uint32_t v, bool keep_min) {
+	if constexpr (S == 16u || S == 32u) {
+		uint32_t x, y;
+		if constexpr (S == 16u) {
+			const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); // (rows 0 0 2 2 | rows 1 1 3 3)
+			x = r[0], y = r[1];
+		} else {
+			const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); // (lower half twice | upper half twice)
+			x = r[0], y = r[1];
+		}
+		return keep_min ? min(x, y) : max(x, y);
+	} else {
+		uint32_t p;
+		if constexpr (S == 1u)
+			p = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false); // quad_perm [1, 0, 3, 2]
+		else if constexpr (S == 2u)
+			p = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, false); // quad_perm [2, 3, 0, 1]
+		else if constexpr (S == 4u) {
+			p = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false); // row_shl:4 into the quads 0 and 2 of a row
+			p = (uint32_t)__builtin_amdgcn_update_dpp((int)p, (int)v, 0x114, 0xF, 0xA, false); // row_shr:4 into the quads 1 and 3
+		} else {
+			static_assert(S == 8u, "lane distance");
+			p = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, false); // row_ror:8
+		}
+		return keep_min ? min(v, p) : max(v, p);
+	}
+}
+
+// stage (K, J) of the bitonic network over CAP keys, EPT consecutive ones per thread, and all the stages behind it (the
+// recursion is the compile-time loop nest: every stage has its own code)
+template <uint32_t CAP, uint32_t EPT, uint32_t K, uint32_t J> __device__ __forceinline__ void bitonic_stages(uint32_t (&v)[EPT], const uint32_t t, uint32_t *s_x) {
+	if constexpr (J < EPT) { // inside the thread
+#pragma unroll
+		for (uint32_t i = 0; i < EPT; ++i) {
+			const uint32_t l = i ^ J;
+			if (l > i) {
+				const bool up = K >= EPT ? ((t * EPT) & K) == 0u : (i & K) == 0u;
+				const uint32_t x = v[i], y = v[l], mn = min(x, y), mx = max(x, y);
+				v[i] = up ? mn : mx;
+				v[l] = up ? mx : mn;
+			}
+		}
+	} else { // a whole register set against the one of thread t ^ (J / EPT)
+		constexpr uint32_t S = J / EPT;
+		const bool keep_min = (((t & S) == 0u) == (((t * EPT) & K) == 0u));
+		if constexpr (S < 64u) {
+#pragma unroll
+			for (uint32_t i = 0; i < EPT; ++i) v[i] = lane_xor_minmax<S>(v[i], keep_min);
+		} else {
+			__syncthreads();
+#pragma unroll
+			for (uint32_t i = 0; i < EPT; ++i) s_x[i * 256u + t] = v[i];
+			__syncthreads();
+#pragma unroll
+			for (uint32_t i = 0; i < EPT; ++i) {
+				const uint32_t p = s_x[i * 256u + (t ^ S)];
+				v[i] = keep_min ? min(v[i], p) : max(v[i], p);
+			}
+		}
+	}
+	if constexpr (J > 1u)
+		bitonic_stages<CAP, EPT, K, J / 2u>(v, t, s_x);
+	else if constexpr (K < CAP)
+		bitonic_stages<CAP, EPT, 2u * K, K>(v, t, s_x);
+}
+
+// CAP = BLK_CAP: every tile, one workgroup each; a tile that does not fit is appended to big_list ([0] = count) instead.
+// CAP = BLK_CAP_BIG: the listed tiles, a workgroup taking every gridDim.x-th of them.
+// The bitonic network runs on EPT = CAP / 256 consecutive keys per thread held in registers: strides below EPT are compare-
+// exchanges inside a thread, strides up to 32 EPT exchange whole register sets between lanes of a wave (xor shuffles), and only
+// the last strides (two or three stages of the whole network) go through LDS and a barrier.  (The first version -- every stage
+// through LDS, 66 barriers -- took 357 us per 15 M points; the radix passes it replaces take 500.)
+template <uint32_t CAP> __global__ __launch_bounds__(256) void k_block_sort(const uint32_t *__restrict__ keys, const float4 *__restrict__ rec, uint32_t n,
+                                                     const uint32_t *__restrict__ start7, const uint32_t *__restrict__ end7, const uint32_t *__restrict__ dest_h,
+                                                     uint32_t *__restrict__ out_keys, uint32_t *__restrict__ out_perm, float4 *__restrict__ out_rec,
+                                                     uint32_t *__restrict__ big_list) {
+	constexpr uint32_t EPT = CAP / 256u;
+	__shared__ uint16_t s_lut[24 * 8];
+	__shared__ uint32_t s_x[CAP];     // exchange buffer of the widest strides, [register][thread]
+	__shared__ uint32_t s_hil[CAP];   // Hilbert index of the element at a position in the tile
+	__shared__ uint32_t s_base[CAP];  // destination of its block minus the block's offset in the tile
+	if (threadIdx.x < 24 * 8) {
+		constexpr uint16_t LUT[24 * 8] = {TREEE_HILBERT_LUT_INIT};
+		s_lut[threadIdx.x] = LUT[threadIdx.x];
+	}
+	const uint32_t t = threadIdx.x;
+	for (uint32_t turn = blockIdx.x;; turn += gridDim.x) {
+		uint32_t tile = turn;
+		if constexpr (CAP != BLK_CAP) {
+			if (turn >= big_list[0]) return; // (uniform)
+			tile = big_list[1u + turn];
+		}
+		// the whole blocks that START in [a, b): a block that straddles a belongs to the tile before, one that straddles b to this one
+		const uint32_t a = tile * BLK_TILE, b = min(n, a + BLK_TILE);
+		uint32_t lo = a, hi = b;
+		{
+			const uint32_t m = keys[a] >> 9;
+			if (start7[m] != a) lo = end7[m];
+			if (b < n) {
+				const uint32_t mb = keys[b] >> 9;
+				if (start7[mb] != b) hi = end7[mb];
+			}
+		}
+		const uint32_t n_loc = hi > lo ? hi - lo : 0u; // (<= BLK_CAP_BIG: every block is shorter than BLOCK7_MAX)
+		if constexpr (CAP == BLK_CAP) {
+			if (n_loc > CAP) { // (uniform) left to the second launch
+				if (t == 0) big_list[1u + atomicAdd(&big_list[0], 1u)] = tile;
+				return;
+			}
+		}
+		__syncthreads(); // the table is there; the arrays of the tile before are free
+		// composite keys, all distinct: block's offset in the tile << 20 | low 9 Hilbert bits << 11 | position in the block (< 2^11).
+		// Global memory is touched lane-contiguously (element i * 256 + t); the network wants EPT consecutive keys per thread:
+		// the keys pass through s_x on the way in and on the way out.
+#pragma unroll
+		for (uint32_t i = 0; i < EPT; ++i) {
+			const uint32_t e = i * 256u + t;
+			uint32_t sk = 0xFFFFFFFFu;
+			if (e < n_loc) {
+				const uint32_t key = keys[lo + e], m = key >> 9;
+				const uint32_t h = hilbert_of_morton_lut(key, s_lut), brel = start7[m] - lo;
+				s_hil[e] = h;
+				s_base[e] = dest_h[h >> 9] - brel;
+				sk = (brel << 20) | ((h & 511u) << 11) | (e - brel);
+			}
+			s_x[e] = sk;
+		}
+		__syncthreads();
+		uint32_t v[EPT];
+#pragma unroll
+		for (uint32_t i = 0; i < EPT; ++i) v[i] = s_x[t * EPT + i];
+		bitonic_stages<CAP, EPT, 2u, 1u>(v, t, s_x);
+		__syncthreads();
+#pragma unroll
+		for (uint32_t i = 0; i < EPT; ++i) s_x[t * EPT + i] = v[i];
+		__syncthreads();
+		// slot sl of the sorted tile: 64 consecutive slots per wave instruction -- their records lie within one or two blocks of
+		// the input (a window of a few KiB), their destinations are consecutive
+#pragma unroll
+		for (uint32_t i = 0; i < EPT; ++i) {
+			const uint32_t sl = i * 256u + t;
+			if (sl < n_loc) {
+				const uint32_t sk = s_x[sl], e = (sk >> 20) + (sk & 2047u);
+				const uint32_t g = s_base[e] + sl; // block destination + (slot - block offset): the block's slots are [offset, offset + size)
+				const float4 r = rec[lo + e];
+				out_keys[g] = s_hil[e];
+				out_perm[g] = __float_as_uint(r.w);
+				out_rec[g] = r;
+			}
+		}
+		if constexpr (CAP == BLK_CAP) return;
+	}
+}
+
+// *taken = false (nothing written) when the cloud is too small for the tables to pay
+int32_t hilbert_order_by_blocks(treee_ctx *ctx, const SortedCloud *sc, SortedCloud *fine, bool *taken) {
+	const uint32_t n = (uint32_t)sc->n;
+	*taken = false;
+	if (n < 4u * BLK_CELLS / 8u) return TREEE_OK; // (below ~1 M points the 2^21-entry tables cost more than the radix passes)
+	hipStream_t st = ctx->stream;
+	uint32_t *d_start = nullptr, *d_end = nullptr, *d_size_h = nullptr, *d_dest_h = nullptr;
+	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_start));
+	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_end));
+	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_size_h));
+	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_dest_h));
+	TREEE_HIP(hipMemsetAsync(d_start, 0, (size_t)BLK_CELLS * 4, st));
+	TREEE_HIP(hipMemsetAsync(d_end, 0, (size_t)BLK_CELLS * 4, st));
+	hipLaunchKernelGGL(k_block_bounds, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, n, d_start, d_end);
+	hipLaunchKernelGGL(k_block_sizes_hilbert, dim3(BLK_CELLS / 256), dim3(256), 0, st, d_start, d_end, d_size_h);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_size_h, d_dest_h, BLK_CELLS, nullptr));
+	const uint32_t n_tiles = div_up(n, BLK_TILE);
+	uint32_t *d_big = nullptr; // [0] = number of tiles left to the second launch, then their indices
+	TREEE_TRY(ctx->alloc_t((size_t)n_tiles + 1, &d_big));
+	TREEE_HIP(hipMemsetAsync(d_big, 0, 4, st));
+	hipLaunchKernelGGL(k_block_sort<BLK_CAP>, dim3(n_tiles), dim3(256), 0, st, sc->d_keys, sc->d_sorted, n, d_start, d_end, d_dest_h, fine->d_keys, fine->d_perm,
+	                   fine->d_sorted, d_big);
+	hipLaunchKernelGGL(k_block_sort<BLK_CAP_BIG>, dim3(std::min(n_tiles, 512u)), dim3(256), 0, st, sc->d_keys, sc->d_sorted, n, d_start, d_end, d_dest_h, fine->d_keys,
+	                   fine->d_perm, fine->d_sorted, d_big);
+	TREEE_LAUNCH_CHECK();
+	*taken = true;
+	return TREEE_OK;
+}
+
 // The kNN structure's own order.  The shared sort is by Morton key (it is also the octree's); the kNN structure re-sorts a
 // private copy of the cloud by the HILBERT index of the same 10-bit cells: a bucket of 64 consecutive points is then one
 // contiguous blob instead of, every so often, two pieces on either side of a jump of the Z curve, and its queries share
@@ -1506,8 +1775,9 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 		TREEE_HIP(hipMemcpyAsync(h, d_flag, 4, hipMemcpyDeviceToHost, st));
 		TREEE_TRY(cube_fetch_async(ctx, sc.get(), h_cube));
 		TREEE_HIP(hipStreamSynchronize(st));
-		flag = h[0];
+		flag = h[0] & 1u;
 		sc->crowded = (int)flag;
+		sc->block7_big = (int)((h[0] >> 1) & 1u);
 		cube_commit(sc.get(), h_cube);
 	}
 	static const bool morton_order = getenv("TREEE_KNN_MORTON") != nullptr; // A/B hook: keep the shared Morton order
@@ -1526,6 +1796,17 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 	if (!flag && !morton_order && !sc->hilbert && !no_cells && sc->cell_share >= 0.0f && sc->cell_share <= 0.4f) {
 		bool taken = false;
 		TREEE_TRY(hilbert_order_by_cells(ctx, sc.get(), fine.get(), &taken));
+		if (taken) {
+			*out = fine;
+			return TREEE_OK;
+		}
+	}
+	static const bool no_blocks = getenv("TREEE_KNN_NO_BLOCKSORT") != nullptr; // A/B and test hook: always the radix passes
+	static const bool trace = getenv("TREEE_KNN_TRACE") != nullptr;
+	if (trace) fprintf(stderr, "[treee knn order] n=%llu crowded=%d block7_big=%d cell_share=%.3f hilbert=%d\n", (unsigned long long)n, sc->crowded, sc->block7_big, sc->cell_share, (int)sc->hilbert);
+	if (!flag && !morton_order && !sc->hilbert && !no_blocks && sc->block7_big == 0) {
+		bool taken = false;
+		TREEE_TRY(hilbert_order_by_blocks(ctx, sc.get(), fine.get(), &taken));
 		if (taken) {
 			*out = fine;
 			return TREEE_OK;
@@ -1690,6 +1971,7 @@ int32_t build_segmented(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_se
 			TREEE_HIP(hipMemcpyAsync(&flag, d_err, 4, hipMemcpyDeviceToHost, st));
 			TREEE_HIP(hipStreamSynchronize(st));
 			TREEE_HIP(hipMemsetAsync(d_err, 0, 4, st));
+			flag &= 1u; // (bit 1 is about 2^-7 blocks of MORTON-sorted keys: not this structure's business)
 		}
 		if (flag) {
 			uint32_t *d_lo = d_sk, *d_lo_s = d_sks, *d_pos1 = d_perm2, *d_hi = d_keys; // buffers that are free at this point

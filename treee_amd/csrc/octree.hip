@@ -239,7 +239,8 @@ int32_t build_octree_on(treee_ctx *ctx, treee_octree *o) {
 	const uint32_t lod_total = h[3];
 	o->n_nodes = (uint64_t)h[1] + h[2];
 	o->n_lod = lod_total;
-	o->sc->crowded = (int)h[0];
+	o->sc->crowded = (int)(h[0] & 1u);
+	o->sc->block7_big = (int)((h[0] >> 1) & 1u);
 	o->sc->cell_share = h[9] ? (float)h[8] / (float)h[9] : 1.0f;
 	cube_commit(o->sc.get(), h_cube);
 	const uint32_t nn = (uint32_t)o->n_nodes;
@@ -640,7 +641,8 @@ int32_t treee_sort_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const flo
 		if (rc == TREEE_OK) rc = cube_fetch_async(ctx, sc, h_cube);
 		if (rc == TREEE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_dev: synchronise");
 		if (rc == TREEE_OK) {
-			sc->crowded = (int)h[0];
+			sc->crowded = (int)(h[0] & 1u);
+			sc->block7_big = (int)((h[0] >> 1) & 1u);
 			sc->cell_share = h[9] ? (float)h[8] / (float)h[9] : 1.0f;
 			cube_commit(sc, h_cube);
 		}

@@ -497,9 +497,16 @@ void SortedCloud::release() {
 // every LONG_RUN_STEP-th position is probed: a run longer than LONG_RUN + LONG_RUN_STEP is always found, one
 // between LONG_RUN and that may or may not be (the threshold is a heuristic, the probe a 64th of the reads)
 constexpr uint32_t LONG_RUN_STEP = 64;
+// bit 0: a run of more than LONG_RUN equal keys (a crowded 2^-10 cell); bit 1: a run of BLOCK7_PROBE + 1 or more keys that
+// share their top 21 bits (a 2^-7 block that may hold BLOCK7_MAX points or more: hilbert_order_by_blocks, knn.hip, sorts
+// tiles of whole blocks in LDS and needs every block below that) -- every run of BLOCK7_MAX is found, shorter ones down to
+// BLOCK7_PROBE may be
 __global__ __launch_bounds__(256) void k_long_run(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ flag) {
 	const uint64_t i = (uint64_t)(blockIdx.x * 256u + threadIdx.x) * LONG_RUN_STEP;
-	if (i + LONG_RUN < n && keys[i] == keys[i + LONG_RUN]) *flag = 1u; // benign race: every writer stores 1
+	uint32_t bits = 0u;
+	if (i + LONG_RUN < n && keys[i] == keys[i + LONG_RUN]) bits |= 1u;
+	if (i + BLOCK7_PROBE < n && (keys[i] >> 9) == (keys[i + BLOCK7_PROBE] >> 9)) bits |= 2u;
+	if (bits && (*flag & bits) != bits) atomicOr(flag, bits); // (the plain read keeps a crowded cloud from queueing its atomics on one word)
 }
 
 int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t *d_flag) {
