@@ -31,6 +31,7 @@ struct treee_knn {
 	uint32_t nb = 0;       // buckets of 64 points
 	uint32_t P = 1;        // leaves padded to a power of two; node i: children 2i, 2i+1; leaf b = P + b
 	float4 *d_bvh = nullptr; // [2P][2] : (min.xyz, min segment), (max.xyz, max segment); segments are 0 unless `segmented`
+	float4 *d_sub = nullptr; // [nb][4][2]: (min.xyz, -), (max.xyz, -) of every quarter (16 consecutive records) of a bucket
 	bool segmented = false;  // buckets never straddle a segment; a query only sees its own segment (build_segmented)
 	uint64_t n_points = 0;   // points the handle was built from (sc->n counts the padding of a segmented handle too)
 	uint32_t *d_order = nullptr; // workgroup -> bucket of the self-query kernel (build_bvh), ~0u = padding
@@ -48,7 +49,8 @@ constexpr int BUCKET = 64;
 // 16 lanes per bucket, 4 consecutive records per lane (64 contiguous bytes): a wave covers 4 buckets = 4 KiB, the
 // per-lane fold needs no cross-lane traffic and the butterfly has 4 steps instead of 6.
 __global__ __launch_bounds__(256) void k_leaf_aabb(const float4 *__restrict__ pts, uint32_t n, uint32_t nb, uint32_t P,
-                                                    const uint32_t *__restrict__ bucket_seg /* or null */, float4 *__restrict__ bvh) {
+                                                    const uint32_t *__restrict__ bucket_seg /* or null */, float4 *__restrict__ bvh,
+                                                    float4 *__restrict__ sub) {
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	const uint32_t b = t >> 4; // bucket
 	if (b >= P) return;        // whole groups of 16 lanes leave together (the shuffles below stay inside a group)
@@ -69,10 +71,23 @@ __global__ __launch_bounds__(256) void k_leaf_aabb(const float4 *__restrict__ pt
 			}
 		}
 	}
+	// four lanes = one quarter of the bucket (16 consecutive records): its box first (the scans skip a quarter no query needs),
+	// then the bucket's (min / max are exact: the order of the folds does not matter)
 #pragma unroll
 	for (int a = 0; a < 3; ++a)
 #pragma unroll
-		for (int o = 8; o > 0; o >>= 1) {
+		for (int o = 1; o <= 2; o <<= 1) {
+			mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+			mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+		}
+	if ((t & 3u) == 0 && b < nb) {
+		sub[8ull * b + 2u * ((t & 15u) >> 2) + 0] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+		sub[8ull * b + 2u * ((t & 15u) >> 2) + 1] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+	}
+#pragma unroll
+	for (int a = 0; a < 3; ++a)
+#pragma unroll
+		for (int o = 4; o <= 8; o <<= 1) {
 			mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
 			mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
 		}
@@ -204,6 +219,7 @@ __device__ __forceinline__ void fast_eigenvalues(const float mat[3][3], float ou
 struct KnnArgs {
 	const float4 *pts; // sorted records (x,y,z,bitcast(orig))
 	const float4 *bvh;
+	const float4 *sub; // [nb][4][2] quarter boxes of the buckets
 	uint32_t n, nb, P;
 	// queries: self mode (q_xyz == nullptr): query j = pts[j], output row = orig index
 	const float *q_xyz;          // AoS, original order
@@ -498,7 +514,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define TREEE_NG 4
 #endif
 #ifndef TREEE_GROUP
-#define TREEE_GROUP 56 // listed buckets whose boxes are in LDS at a time: 56 and not 64 keeps the workgroup's LDS at 12 800 bytes (below)
+#define TREEE_GROUP 52 // listed buckets whose boxes are in LDS at a time: 52 (+ the 128 bytes of quarter boxes) keeps the workgroup's LDS at 12 800 bytes (below)
 #endif
 #ifndef TREEE_ORDER_RANGE
 #define TREEE_ORDER_RANGE 128
@@ -527,6 +543,7 @@ struct KnnLds {
 	uint32_t buf[2 * SBUF * 64];          // [pos | distance bits][slot][lane]: conflict-free per slot
 	uint32_t s_list[LIST_CAP];            // candidate buckets of the wave
 	float4 s_gbox[TREEE_GROUP][2];        // boxes of the current group of listed buckets
+	float4 s_sub[4][2];                   // quarter boxes of the bucket about to be scanned by all lanes
 };
 __device__ __forceinline__ KnnLds &knn_lds() {
 	__shared__ __attribute__((aligned(16))) KnnLds s;
@@ -551,6 +568,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	auto &s_list = lds.s_list;
 	constexpr uint32_t GROUP = TREEE_GROUP; // listed buckets whose boxes are in LDS at a time
 	auto &s_gbox = lds.s_gbox;
+	auto &s_sub = lds.s_sub;
 	// LDS is handed out in units of 1 280 bytes (160 KB / 128): 12 workgroups per CU -- the 3 waves per SIMD the registers
 	// allow -- fit only if each takes at most 10 units.  With 13 056 bytes (GROUP = 64) a CU held 11: measured 8.78 instead
 	// of 8.27 ms (12 800 and 12 928 bytes differ by exactly that step).
@@ -646,72 +664,57 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	};
 	// all 64 candidates of the staged tile against this lane's query; packed f32 math, two
 	// candidates per instruction; the append is branch-free (write always, count if it passes)
-	auto scan_tile = [&](uint32_t base, uint64_t lanes, int first) __attribute__((always_inline)) {
+	// `quarters`: bit q set = candidates [16 q, 16 q + 16) are scanned (wave-uniform; a quarter whose box no lane's search ball
+	// reaches is left out: profiles/sim counts 27 % of the quarters of the buckets that come through here).  Runs of adjacent
+	// quarters are scanned as one piece, so a bucket needed in full costs what it did.
+	auto scan_tile = [&](uint32_t base, uint64_t lanes, int first, uint32_t quarters) __attribute__((always_inline)) {
 		const bool act = (lanes >> lane) & 1ull; // lanes outside `lanes` must not append (they saw this bucket already)
-#if TREEE_SCAN_PIPE
-		// software pipeline: the broadcast reads of the NEXT four candidates are issued as soon as this trip's distances
-		// exist (their registers are free again) and are in flight during the append -- the LDS round trip at the head
-		// of every trip is what a trip waits for
 		static_assert(SCHUNK == 4, "the pipelined scan reads 4 candidates per trip");
-		v4f nx = *(const v4f *)&tile[0][first], ny = *(const v4f *)&tile[1][first], nz = *(const v4f *)&tile[2][first];
+		quarters &= 0xFu << (first >> 4);
 #pragma unroll 1
-		for (int c0 = first; c0 < BUCKET; c0 += SCHUNK) {
-			if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
-			uint32_t db[SCHUNK];
-			{
-				const v2f cx0 = {nx.x, nx.y}, cx1 = {nx.z, nx.w}, cy0 = {ny.x, ny.y}, cy1 = {ny.z, ny.w}, cz0 = {nz.x, nz.y}, cz1 = {nz.z, nz.w};
-				const v2f dx0 = cx0 - qx2, dy0 = cy0 - qy2, dz0 = cz0 - qz2, dx1 = cx1 - qx2, dy1 = cy1 - qy2, dz1 = cz1 - qz2;
-				const v2f d0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, d1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1; // metric.rs:21-26
-				db[0] = __float_as_uint(d0.x);
-				db[1] = __float_as_uint(d0.y);
-				db[2] = __float_as_uint(d1.x);
-				db[3] = __float_as_uint(d1.y);
-			}
-			{
-				const int cn = c0 + SCHUNK < BUCKET ? c0 + SCHUNK : c0; // (the last trip re-reads its own candidates: no branch)
-				nx = *(const v4f *)&tile[0][cn];
-				ny = *(const v4f *)&tile[1][cn];
-				nz = *(const v4f *)&tile[2][cn];
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // keeps the reads above the append
-			}
+		while (quarters) {
+			const int q0 = __builtin_ctz(quarters), qn = __builtin_ctz(~(quarters >> q0)); // first quarter of the run, its length
+			quarters &= ~(((1u << qn) - 1u) << q0);
+			const int begin = q0 * 16, end = begin + qn * 16;
+			// software pipeline: the broadcast reads of the NEXT four candidates are issued as soon as this trip's distances
+			// exist (their registers are free again) and are in flight during the append -- the LDS round trip at the head
+			// of every trip is what a trip waits for
+			v4f nx = *(const v4f *)&tile[0][begin], ny = *(const v4f *)&tile[1][begin], nz = *(const v4f *)&tile[2][begin];
+#pragma unroll 1
+			for (int c0 = begin; c0 < end; c0 += SCHUNK) {
+				if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
+				uint32_t db[SCHUNK];
+				{
+					const v2f cx0 = {nx.x, nx.y}, cx1 = {nx.z, nx.w}, cy0 = {ny.x, ny.y}, cy1 = {ny.z, ny.w}, cz0 = {nz.x, nz.y}, cz1 = {nz.z, nz.w};
+					const v2f dx0 = cx0 - qx2, dy0 = cy0 - qy2, dz0 = cz0 - qz2, dx1 = cx1 - qx2, dy1 = cy1 - qy2, dz1 = cz1 - qz2;
+					const v2f d0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, d1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1; // metric.rs:21-26
+					db[0] = __float_as_uint(d0.x);
+					db[1] = __float_as_uint(d0.y);
+					db[2] = __float_as_uint(d1.x);
+					db[3] = __float_as_uint(d1.y);
+				}
+				{
+					const int cn = c0 + SCHUNK < end ? c0 + SCHUNK : c0; // (the last trip re-reads its own candidates: no branch)
+					nx = *(const v4f *)&tile[0][cn];
+					ny = *(const v4f *)&tile[1][cn];
+					nz = *(const v4f *)&tile[2][cn];
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // keeps the reads above the append
+				}
 #pragma unroll
-			for (int j = 0; j < SCHUNK; ++j) { // coarse filter; the merge applies the full (distance, position) order
-				char *w = (char *)buf + wofs;
-				*(uint32_t *)w = base + c0 + j;
-				*(uint32_t *)(w + DB_OFS) = db[j];
-				wofs += (db[j] <= thr && act) ? 256u : 0u;
+				for (int j = 0; j < SCHUNK; ++j) { // coarse filter; the merge applies the full (distance, position) order
+					char *w = (char *)buf + wofs;
+					*(uint32_t *)w = base + c0 + j;
+					*(uint32_t *)(w + DB_OFS) = db[j];
+					wofs += (db[j] <= thr && act) ? 256u : 0u;
+				}
 			}
 		}
-#else
-#pragma unroll 1
-		for (int c0 = first; c0 < BUCKET; c0 += SCHUNK) {
-			if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
-			uint32_t db[SCHUNK];
-#pragma unroll
-			for (int j = 0; j < SCHUNK; j += 2) {
-				const v2f cx = *(const v2f *)&tile[0][c0 + j]; // same address in every lane: LDS broadcast
-				const v2f cy = *(const v2f *)&tile[1][c0 + j];
-				const v2f cz = *(const v2f *)&tile[2][c0 + j];
-				const v2f dx = cx - qx2, dy = cy - qy2, dz = cz - qz2;
-				const v2f d = (dx * dx + dy * dy) + dz * dz; // metric.rs:21-26 (0 + dx*dx == dx*dx exactly)
-				db[j] = __float_as_uint(d.x);
-				db[j + 1] = __float_as_uint(d.y);
-			}
-#pragma unroll
-			for (int j = 0; j < SCHUNK; ++j) { // coarse filter; the merge applies the full (distance, position) order
-				char *w = (char *)buf + wofs;
-				*(uint32_t *)w = base + c0 + j;
-				*(uint32_t *)(w + DB_OFS) = db[j];
-				wofs += (db[j] <= thr && act) ? 256u : 0u;
-			}
-		}
-#endif
 		__syncthreads();
 	};
 	auto scan_bucket = [&](uint32_t b) __attribute__((always_inline)) {
 		if (b * BUCKET >= a.n) return;
 		stage(load_bucket(b));
-		scan_tile(b * BUCKET, ~0ull, 0);
+		scan_tile(b * BUCKET, ~0ull, 0, 0xFu);
 	};
 	// lanes (queries) whose search ball still reaches the box
 	auto lane_box_hit = [&](float lox, float loy, float loz, float hix, float hiy, float hiz) __attribute__((always_inline)) -> uint64_t {
@@ -720,6 +723,24 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		const float dz = fmaxf(fmaxf(loz - qz, qz - hiz), 0.0f);
 		const float bd = (dx * dx + dy * dy) + dz * dz;
 		return __ballot(live && __float_as_uint(bd) <= thr);
+	};
+
+	// Quarters of a bucket some lane's search ball still reaches (a wave-uniform 4-bit mask).  Lanes 0 .. 7 fetch one corner
+	// each of the bucket's four quarter boxes (k_leaf_aabb) -- together with the bucket's records, so that the test adds no
+	// round trip --; through LDS the corners become broadcast operands of the per-lane box test.
+	auto sub_load = [&](uint32_t b) __attribute__((always_inline)) -> float4 {
+		return lane < 8 ? a.sub[8ull * b + (uint32_t)lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	};
+	auto quarters_needed = [&](const float4 &sv) __attribute__((always_inline)) -> uint32_t {
+		if (lane < 8) (&s_sub[0][0])[lane] = sv;
+		__syncthreads();
+		uint32_t m = 0u;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const float4 lo = s_sub[q][0], hi = s_sub[q][1]; // same address in every lane: LDS broadcast
+			m |= lane_box_hit(lo.x, lo.y, lo.z, hi.x, hi.y, hi.z) ? 1u << q : 0u;
+		}
+		return m;
 	};
 
 	if (start >= a.nb) start = a.nb - 1;
@@ -740,9 +761,12 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		if constexpr (SEG) {
 			if (t > 0 && __float_as_uint(a.bvh[2ull * (a.P + b)].w) != myseg) continue; // Morton neighbour of another segment
 		}
+		const float4 sv = sub_load(b);
 		stage(load_bucket(b));
 		const uint32_t base = b * BUCKET;
 		int first = 0;
+		uint32_t quarters = 0xFu;
+		if (t > 0) quarters = quarters_needed(sv);
 		if (t == 0) {
 			// against an unbounded threshold everything passes, so the first 32 records go straight into
 			// the list (one 240-CE sort instead of eight buffer merges)
@@ -762,7 +786,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			ST(if (a.thr_io && a.thr_seed && live) thr = min(thr, a.thr_io[slot]));
 			first = SK;
 		}
-		scan_tile(base, ~0ull, first);
+		scan_tile(base, ~0ull, first, quarters);
 		ST(st_buckets++);
 	}
 	if (__any(wofs != wofs0)) flush(); // threshold = 32nd best inside the own bucket
@@ -937,9 +961,10 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			// but pins the load above it.  The value stays an ordinary compiler-tracked register value:
 			// the compiler places the vmcnt wait at the use (an earlier version issued the load from inline
 			// asm and waited by hand, which faults as soon as the allocator copies the in-flight registers).
-			float4 pf = make_float4(nanv, nanv, nanv, 0.0f);
+			float4 pf = make_float4(nanv, nanv, nanv, 0.0f), pf_sub = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			auto issue_prefetch = [&](uint32_t jj) __attribute__((always_inline)) {
 				pf = *bucket_ptr(jj);
+				pf_sub = sub_load(listed(jj));
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			};
 			if (j < gcount) issue_prefetch(j);
@@ -952,7 +977,11 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 				const bool small = __popcll(need_cur) < TRANSPOSE_BELOW;
 				// order matters: consume this bucket's registers (LDS staging) BEFORE the next load is issued,
 				// otherwise the wait for `cand` also drains the prefetch and exposes its latency
-				if (!small) stage(cand);
+				uint32_t quarters = 0xFu;
+				if (!small) {
+					stage(cand);
+					quarters = quarters_needed(pf_sub);
+				}
 				PH(8);
 				j = find_next(j + 1, need);
 				if (j < gcount) issue_prefetch(j); // in flight during the scan below
@@ -998,7 +1027,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 				PH(3);
 				if (full) {
 					if (small) stage(cand); // deferred queries of a transposed bucket (rare)
-					scan_tile(leaf * BUCKET, full, 0);
+					scan_tile(leaf * BUCKET, full, 0, quarters);
 				}
 				PH(4);
 				ST(st_buckets++);
@@ -1232,6 +1261,7 @@ int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint
 	KnnArgs a;
 	a.pts = t->sc->d_sorted;
 	a.bvh = t->d_bvh;
+	a.sub = t->d_sub;
 	a.n = (uint32_t)t->sc->n;
 	a.nb = t->nb;
 	a.P = t->P;
@@ -1895,7 +1925,8 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t, const uint32_t *d_bucket_seg = n
 	while (t->P < t->nb) t->P <<= 1;
 	t->owner = ctx;
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->P * 2 * 2, &t->d_bvh));
-	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 16)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, d_bucket_seg, t->d_bvh);
+	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->nb * 8, &t->d_sub));
+	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 16)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, d_bucket_seg, t->d_bvh, t->d_sub);
 	uint32_t lvl = t->P >> 1;
 	for (; lvl > INNER_TOP; lvl >>= 1) // nodes [lvl, 2*lvl)
 		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
@@ -2208,6 +2239,7 @@ int32_t treee_knn_free(treee_knn *t) {
 	retire(t->owner, &t->sync);
 	t->sc.reset();
 	pool_release(t->owner, t->d_bvh);
+	pool_release(t->owner, t->d_sub);
 	pool_release(t->owner, t->d_order);
 	delete t;
 	return TREEE_OK;
