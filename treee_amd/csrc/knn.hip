@@ -399,7 +399,7 @@ constexpr int SBUF = TREEE_SBUF;   // buffer slots per lane (power of two <= SK)
 #endif
 constexpr int SCHUNK = TREEE_SCHUNK; // candidates scanned between flush checks (flush when < SCHUNK slots are free)
 #ifndef TREEE_TRANSPOSE_BELOW
-#define TREEE_TRANSPOSE_BELOW 20
+#define TREEE_TRANSPOSE_BELOW 12 // (20 until the lane-parallel scans began to skip quarters, round 4: 6 / 8 / 10 / 12 / 16 / 20 / 24 needing lanes: 7.91 / 7.82 / 7.73 / 7.72 / 7.73 / 7.83 / 7.95 ms)
 #endif
 constexpr int TRANSPOSE_BELOW = TREEE_TRANSPOSE_BELOW; // buckets needed by fewer queries are scanned transposed
 // Keys are distance bits << 32 | sorted position.  Distances are >= +0 and at most +inf (0x7F800000), so read as
