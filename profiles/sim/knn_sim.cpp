@@ -115,6 +115,26 @@ struct Wave {
 			buf[l].reserve(SBUF);
 		}
 	}
+	int tighten_mode = 0; // 1: after every bucket thr = min(thr, max(L[31 - m], largest pending)); 2: the exact 32nd of list + pending
+	void tighten() {
+		if (!tighten_mode) return;
+		for (int l = 0; l < 64; ++l) {
+			const size_t m = buf[l].size();
+			if (!m) continue;
+			if (tighten_mode == 1) {
+				uint32_t pmax = 0;
+				for (uint64_t e : buf[l]) pmax = std::max(pmax, (uint32_t)(e >> 32));
+				const uint32_t lm = (uint32_t)(L[l][SK - 1 - std::min<size_t>(m, SK - 1)] >> 32);
+				thr[l] = std::min(thr[l], std::max(lm, pmax));
+			} else {
+				uint64_t tmp[SK + 4 * SBUF];
+				memcpy(tmp, L[l], sizeof(uint64_t) * SK);
+				memcpy(tmp + SK, buf[l].data(), sizeof(uint64_t) * m);
+				std::nth_element(tmp, tmp + SK - 1, tmp + SK + m);
+				thr[l] = std::min(thr[l], (uint32_t)(tmp[SK - 1] >> 32));
+			}
+		}
+	}
 	int pair_xor = 0; // > 0: lanes l and l ^ pair_xor share 2 x SBUF slots
 	int sbuf = SBUF;
 	bool any_pending(size_t more_than) const {
@@ -291,6 +311,7 @@ struct Wave {
 			quarter_stats(b);
 			scan_tile(b, ~0ull, 0);
 			k.buckets += 1;
+			tighten();
 		}
 		if (any_pending(0)) flush();
 		phase = 2;
@@ -327,6 +348,7 @@ struct Wave {
 				quarter_stats(leaf);
 				scan_tile(leaf, ~0ull, 0);
 			}
+			tighten();
 		}
 		if (any_pending(0)) flush();
 		k.waves += 1;
@@ -451,10 +473,12 @@ int main(int argc, char **argv) {
 	struct Variant {
 		std::string name;
 		int kind, SUB, C, nbr_pre, nbr_total, lazy, tb;
-		int pair_xor = 0, sbuf = SBUF;
+		int pair_xor = 0, sbuf = SBUF, tighten = 0;
 	};
 	std::vector<Variant> vs = {
 	    {"cur nbr4 tb20", 0, 0, 0, 4, 4, 0, 20},
+	    {"cur tighten max(L[31-m],pmax)", 0, 0, 0, 4, 4, 0, 20, 0, 16, 1},
+	    {"cur tighten exact per bucket", 0, 0, 0, 4, 4, 0, 20, 0, 16, 2},
 	    {"cur pair l^32", 0, 0, 0, 4, 4, 0, 20, 32, 16},
 	    {"cur pair l^1", 0, 0, 0, 4, 4, 0, 20, 1, 16},
 	    {"cur pair l^16", 0, 0, 0, 4, 4, 0, 20, 16, 16},
@@ -484,6 +508,7 @@ int main(int argc, char **argv) {
 				Wave w(c, k, b);
 				w.pair_xor = v.pair_xor;
 				w.sbuf = v.sbuf;
+				w.tighten_mode = v.tighten;
 				if (v.kind == 0)
 					w.run_current(v.nbr_total, v.tb);
 				else
