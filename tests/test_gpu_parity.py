@@ -205,7 +205,11 @@ def test_knn_structure_from_an_octree_orders_cells_like_the_point_sort(T):
     # Hilbert order from tiles of whole blocks sorted in LDS (hilbert_order_by_blocks, round 4) -- the benchmark cloud's path
     big, _ = synth.forest_cloud(1_300_000, plot=200.0 * (1.3 / 15.0) ** 0.5)
     big_dup = np.concatenate([big[:1_100_000], big[:150_000], big[400_000:450_000]])
-    for name, pts in (("forest", forest), ("duplicates", dup), ("uniform", uniform), ("lattice", lattice), ("blocks", big), ("blocks_duplicates", big_dup)):
+    # a thin slab: ~3 300 occupied 2^-7 blocks of ~450 points, some beyond 512 -- their tiles take the second launch with twice the LDS
+    rng = np.random.default_rng(41)
+    slab = (rng.random((1_500_000, 3)) * np.array([1.0, 0.01, 0.1])).astype(np.float32)
+    for name, pts in (("forest", forest), ("duplicates", dup), ("uniform", uniform), ("lattice", lattice), ("blocks", big), ("blocks_duplicates", big_dup),
+                      ("blocks_slab", slab)):
         d_pts = torch.from_numpy(pts).cuda()
         oc = T.Octree(d_pts)
         a = T.KDTree.from_octree(oc)
