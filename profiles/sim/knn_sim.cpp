@@ -89,7 +89,7 @@ struct Counters {
 	       tq = 0 /* transposed (query, bucket) pairs */, tq_pass = 0, boxtests = 0 /* per-lane box tests, wave instructions groups */, bfs_batches = 0,
 	       listed = 0, rounds = 0, evals_useful = 0, subtests = 0, lanes_need_sum = 0, full_scans = 0, small_scans = 0, idle_lane_steps = 0, retests = 0,
 	       max_lane_appended = 0, fill_hist[17] = {}, flush_phase[4] = {}, lanes_over8_at_flush = 0, sum_final_thr_ratio = 0,
-	       q_total = 0, q_zero = 0, q_low = 0, q_need_sum = 0, h_total = 0, h_zero = 0, flush_ce = 0, flush_wide = 0, flush_lo_untouched = 0, flush_lo8_untouched = 0, lanes_lo_touched = 0;
+	       q_total = 0, q_zero = 0, q_low = 0, q_need_sum = 0, h_total = 0, h_zero = 0, flush_ce = 0, flush_wide = 0, flush_lo_untouched = 0, flush_lo8_untouched = 0, lanes_lo_touched = 0, nbr_need_hist[5] = {}, nbr_total = 0;
 	void add(const Counters &o) {
 		double *a = &waves;
 		const double *b = &o.waves;
@@ -309,6 +309,12 @@ struct Wave {
 		phase = 1;
 		for (uint32_t b : nbr_list(nbr)) {
 			quarter_stats(b);
+			{
+				int need = 0;
+				for (int l = 0; l < 64; ++l) need += fbits(box_point(c.bvh[c.P + b], q[l])) <= thr[l];
+				k.nbr_total += 1;
+				k.nbr_need_hist[need == 0 ? 0 : (need < 12 ? 1 : (need < 24 ? 2 : (need < 48 ? 3 : 4)))] += 1;
+			}
 			scan_tile(b, ~0ull, 0);
 			k.buckets += 1;
 			tighten();
@@ -534,6 +540,9 @@ int main(int argc, char **argv) {
 		       total.flushes / W, total.appended / W / 64.0, total.tq / W, total.boxtests / W, total.subtests / W, total.rounds / W, total.retests / W,
 		       total.steps > 0 ? 100.0 * total.idle_lane_steps / (total.steps * 64.0) : 0.0, valu);
 		if (v.kind == 0) printf("   flush compare-exchanges per wave %.0f (wide flushes %.2f) | flushes in which no lane gets an entry below its 16th: %.2f, below its 8th: %.2f; lanes per flush with one below the 16th %.1f\n", total.flush_ce / W, total.flush_wide / W, total.flush_lo_untouched / W, total.flush_lo8_untouched / W, total.lanes_lo_touched / total.flushes);
+		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF && v.tighten == 0)
+			printf("   neighbour buckets by needing lanes: none %.1f%%, 1-11 %.1f%%, 12-23 %.1f%%, 24-47 %.1f%%, 48-64 %.1f%%\n", 100 * total.nbr_need_hist[0] / total.nbr_total,
+			       100 * total.nbr_need_hist[1] / total.nbr_total, 100 * total.nbr_need_hist[2] / total.nbr_total, 100 * total.nbr_need_hist[3] / total.nbr_total, 100 * total.nbr_need_hist[4] / total.nbr_total);
 		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF) {
 			printf("   max-lane appended per wave %.1f | flushes by phase own %.2f nbr %.2f list %.2f | lanes with > 8 pending at a flush %.2f | fill histogram:", total.max_lane_appended / W,
 			       total.flush_phase[0] / W, total.flush_phase[1] / W, total.flush_phase[2] / W, total.lanes_over8_at_flush / total.flushes);
