@@ -60,13 +60,17 @@ __device__ __forceinline__ bool footprint(const SplatParams &P, float x, float y
 	f.rx = fabsf(P.proj[0] * P.scale / w) * (0.5f * fw);
 	f.ry = fabsf(P.proj[5] * P.scale / w) * (0.5f * fh);
 	if (!(f.rx > 0.0f && f.ry > 0.0f)) return false;
-	// pixel px is covered only if sx - rx - 0.5 < px < sx + rx - 0.5; [floor(lower), ceil(upper) + 1) keeps one whole
-	// pixel of slack on either side (the rounding of these sums is < 0.002 px up to 16 K frames), and the coverage test
-	// below -- not this box -- decides: the result does not depend on the box as long as it is a superset
-	f.x0 = clampi(floorf(f.sx - f.rx - 0.5f), 0, (int)P.w);
-	f.x1 = clampi(ceilf(f.sx + f.rx - 0.5f) + 1.0f, 0, (int)P.w);
-	f.y0 = clampi(floorf(f.sy - f.ry - 0.5f), 0, (int)P.h);
-	f.y1 = clampi(ceilf(f.sy + f.ry - 0.5f) + 1.0f, 0, (int)P.h);
+	// Pixel px is covered only if lower < px < upper with lower = sx - rx - 0.5, upper = sx + rx - 0.5 (|u| >= 1 in exact
+	// arithmetic on the floats sx, rx survives the rounding of u and u * u: 1.0 is representable).  The box is the integers of
+	// (lower - SLACK, upper + SLACK): the two float sums are within 0.008 px of the exact ones up to 64 K-pixel frames, SLACK is
+	// twice that.  The coverage test below -- not this box -- decides: the frame does not depend on the box as long as it is a
+	// superset.  (Until round 4 the box kept a whole pixel on either side: a splat of the benchmark frame -- radius 0.47 px --
+	// tested 3 x 3 pixels to cover at most one.)
+	constexpr float SLACK = 0.015625f;
+	f.x0 = clampi(floorf((f.sx - f.rx - 0.5f) - SLACK) + 1.0f, 0, (int)P.w);
+	f.x1 = clampi(ceilf((f.sx + f.rx - 0.5f) + SLACK), 0, (int)P.w);
+	f.y0 = clampi(floorf((f.sy - f.ry - 0.5f) - SLACK) + 1.0f, 0, (int)P.h);
+	f.y1 = clampi(ceilf((f.sy + f.ry - 0.5f) + SLACK), 0, (int)P.h);
 	return f.x0 < f.x1 && f.y0 < f.y1;
 }
 
@@ -134,9 +138,12 @@ __global__ __launch_bounds__(256) void k_splat_points(const void *__restrict__ p
 // side).  A workgroup whose box is larger draws the ordinary way.  min over (depth, original index) is order-free: the
 // frame is the same, bit for bit.
 #ifndef TREEE_SPLAT_PPT
-#define TREEE_SPLAT_PPT 4
+#define TREEE_SPLAT_PPT 2 // (4 until round 4: with footprint boxes that are no wider than they must be, 1 / 2 / 3 / 4 / 6 / 8 records per thread: 0.169 / 0.156 / 0.158 / 0.165 / 0.207 / 0.26 ms)
 #endif
-constexpr int TILE_PX = 2048, TILE_PPT = TREEE_SPLAT_PPT; // pixels of the LDS tile; points per thread (256 * PPT consecutive records per workgroup)
+#ifndef TREEE_SPLAT_TILE_PX
+#define TREEE_SPLAT_TILE_PX 2048
+#endif
+constexpr int TILE_PX = TREEE_SPLAT_TILE_PX, TILE_PPT = TREEE_SPLAT_PPT; // pixels of the LDS tile; points per thread (256 * PPT consecutive records per workgroup)
 __global__ __launch_bounds__(256) void k_splat_tile(const float4 *__restrict__ rec, const uint32_t *__restrict__ value, bool use_value, uint32_t n,
                                                      SplatParams P, unsigned long long *packed, uint32_t *__restrict__ large_count,
                                                      uint32_t *__restrict__ large_list) {
@@ -200,17 +207,29 @@ __global__ __launch_bounds__(256) void k_splat_tile(const float4 *__restrict__ r
 				const float u = (((float)px + 0.5f) - f[k].sx) / f[k].rx;
 				if (!(u * u + v * v < 1.0f)) continue; // point_cloud.wgsl:74-76
 				unsigned long long *q = &s_tile[(py - by0) * bw + (px - bx0)];
+#ifdef TREEE_SPLAT_LDS_PRETEST
 				if (mine[k] < *q) atomicMin(q, mine[k]);
+#else
+				atomicMin(q, mine[k]);
+#endif
 			}
 		}
 	}
 	if (!tiled) return;
 	__syncthreads();
-	for (int t = threadIdx.x; t < area; t += 256) {
+	// slot t = row * bw + col, t = threadIdx.x + 256 i: one division per thread, then (row, col) step by (256 / bw, 256 % bw)
+	const int step_row = 256 / bw, step_col = 256 % bw; // (uniform)
+	int row = (int)threadIdx.x / bw, col = (int)threadIdx.x % bw;
+	for (int t = threadIdx.x; t < area; t += 256, row += step_row, col += step_col) {
+		if (col >= bw) col -= bw, ++row;
 		const unsigned long long best = s_tile[t];
 		if (best == PACKED_CLEAR) continue;
-		unsigned long long *q = packed + (size_t)(by0 + t / bw) * P.w + (bx0 + t % bw);
+		unsigned long long *q = packed + (size_t)(by0 + row) * P.w + (bx0 + col);
+#ifdef TREEE_SPLAT_PRETEST
 		if (best < *q) atomicMin(q, best);
+#else
+		atomicMin(q, best); // (no plain-load test first: the dependent load costs more than the atomics it saves -- 0.168 vs 0.187 ms)
+#endif
 	}
 }
 
