@@ -55,8 +55,10 @@ def parse():
                     "host callbacks over the torch group")
     ap.add_argument("--plot", type=float, default=PLOT, help="edge of the square tile in metres (632 with --points 150000000 keeps the density)")
     ap.add_argument("--halo", type=float, default=2.0)
-    ap.add_argument("--splat-unsorted", action="store_true", help="draw the caller's cloud fragment by fragment (treee_splat_dev, rounds 1-2) instead of the "
-                    "octree's Morton-sorted records through the per-workgroup LDS tile (treee_splat_octree_dev): same frame, 0.31 vs 0.20 ms")
+    ap.add_argument("--splat-unsorted", action="store_true", help="draw the caller's cloud fragment by fragment (treee_splat_dev, rounds 1-2) instead of "
+                    "sorted records through the per-workgroup LDS tile: same frame, slower")
+    ap.add_argument("--splat-octree", action="store_true", help="draw the octree's Morton-sorted records (treee_splat_octree_dev, round 3) instead of the records "
+                    "the kNN structure holds in Hilbert order (treee_splat_knn_dev): same frame, 0.156 vs 0.145 ms")
     ap.add_argument("--no-overlap", action="store_true", help="build the octree's node table and the kNN structure one after the other on one stream")
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="points of the CPU-baseline sample (about 10-30 s of oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,14 +213,18 @@ def main():
         val = stages.run("map_to_u32", lambda: T.map_to_u32_dev(cv, ctx), record)
 
         def splat():
-            # the octree's Morton-sorted records (one 16-byte load per point), resolved in an LDS tile per workgroup before
-            # the frame's atomics; --splat-unsorted draws the caller's cloud as in rounds 1-2.  Same frame either way.
+            # sorted records (one 16-byte load per point), resolved in an LDS tile per workgroup before the frame's atomics: the
+            # kNN structure's, in Hilbert order (--splat-octree: the octree's, in Morton order; --splat-unsorted: the caller's
+            # cloud fragment by fragment as in rounds 1-2).  Same frame every way.
             if args.splat_unsorted:
                 T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), T.context.ptr(val), n, T.context.ptr(view), T.context.ptr(proj),
                                                      env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, 0, None, None))
-            else:
+            elif args.splat_octree:
                 T._lib.check(T.lib().treee_splat_octree_dev(ctx.handle, oc._h, T.context.ptr(val), T.context.ptr(view), T.context.ptr(proj),
                                                             env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, 0, None, None))
+            else:
+                T._lib.check(T.lib().treee_splat_knn_dev(ctx.handle, tree._h, T.context.ptr(val), T.context.ptr(view), T.context.ptr(proj),
+                                                         env.scale, env.min, env.max, W, H, T.context.ptr(packed), 0, 0, None, None))
             T._lib.check(T.lib().treee_splat_resolve_dev(ctx.handle, T.context.ptr(packed), T.context.ptr(val), n, W, H, T.context.ptr(depth),
                                                          T.context.ptr(ids)))
 

@@ -268,6 +268,13 @@ int32_t treee_splat_dev(treee_ctx *ctx, const float *d_xyz_aos, const uint32_t *
 int32_t treee_splat_octree_dev(treee_ctx *ctx, const treee_octree *o, const uint32_t *d_value, const float view[16],
                                const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h,
                                uint64_t *d_packed, int32_t accumulate, uint32_t index_base, float *d_depth, uint32_t *d_id_out);
+/* ... and from the records a kNN structure holds in ITS order (the Hilbert order of the cells: 1 024 consecutive records are a more
+ * compact blob on the screen than along the Z curve -- fewer tiles that do not fit the LDS, 0.156 -> 0.145 ms per 15 M points).
+ * Same frame, bit for bit.  A segmented structure's padding records are skipped.  No reference counterpart (the reference draws
+ * the chunks' own vertex buffers, render/src/point_cloud.rs:148-171). */
+int32_t treee_splat_knn_dev(treee_ctx *ctx, const treee_knn *t, const uint32_t *d_value, const float view[16],
+                            const float proj[16], float scale, uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h,
+                            uint64_t *d_packed, int32_t accumulate, uint32_t index_base, float *d_depth, uint32_t *d_id_out);
 /* resolve a packed buffer (after a cross-GPU min) into depth + id; d_value indexes by the
  * low 32 bits */
 int32_t treee_splat_resolve_dev(treee_ctx *ctx, const uint64_t *d_packed, const uint32_t *d_value,

@@ -126,6 +126,7 @@ def test_multi_gpu_entry_points_validate_their_arguments_without_a_gpu():
     assert L.treee_frame_reduce_min_dev(None, None, None, 0) == 1
     assert L.treee_shard_cube_dev(None, None, None, 0, None, None) == 1
     assert L.treee_splat_octree_dev(None, None, None, None, None, 0.1, 0, 0xFFFFFFFF, 4, 4, None, 0, 0, None, None) == 1
+    assert L.treee_splat_knn_dev(None, None, None, None, None, 0.1, 0, 0xFFFFFFFF, 4, 4, None, 0, 0, None, None) == 1
     pts, seg, out = np.zeros((4, 3), np.float32), np.zeros(4, np.uint32), np.zeros(4, np.float32)
     assert L.treee_curvature_segments_multi(None, 0, pts.ctypes.data_as(C.c_void_p), seg.ctypes.data_as(C.c_void_p), 4, 1, 31, 1.0, out.ctypes.data_as(C.c_void_p)) == 1
 

@@ -553,6 +553,9 @@ def test_splat_from_the_octrees_sorted_records_is_the_same_frame(T, oracle, seed
     val = rng.integers(0, 2**32, len(pts), dtype=np.uint64).astype(np.uint32)
     d_pts, d_val = torch.from_numpy(pts).cuda(), torch.from_numpy(val.view(np.int32)).cuda()
     oc = T.Octree(d_pts)
+    tree = T.KDTree.from_octree(oc)
+    seg2 = np.concatenate([seg, seg[: len(seg) // 2]]).astype(np.int32)
+    seg_tree = T.KDTree.new_segments(d_pts, torch.from_numpy(seg2).cuda(), int(seg2.max()) + 1)
     cloud, prop = T.PointCloud(d_pts), T.PointCloudProperty(d_val)
     for _ in range(3):
         w, h = int(rng.integers(8, 300)), int(rng.integers(8, 200))
@@ -563,6 +566,11 @@ def test_splat_from_the_octrees_sorted_records_is_the_same_frame(T, oracle, seed
         a = cloud.render(prop, view, proj, env, w, h)
         b = cloud.render(prop, view, proj, env, w, h, octree=oc)
         assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[1], b[1])
+        # ... and from the records a kNN structure holds in Hilbert order (treee_splat_knn_dev) -- plain, and segmented (its
+        # padding records (NaN, NaN, NaN, ~0) are no points and must not reach for a value)
+        for tr in (tree, seg_tree):
+            c = cloud.render(prop, view, proj, env, w, h, knn=tr)
+            assert torch.equal(a[0].view(torch.int32), c[0].view(torch.int32)) and torch.equal(a[1], c[1])
         rd, ri, _ = oracle.splat(pts, val, view, proj, env.scale, vmin, vmax, w, h)
         assert np.array_equal(b[0].cpu().numpy().view(np.uint32), rd.view(np.uint32)) and np.array_equal(b[1].cpu().numpy().view(np.uint32), ri)
     # packed output with an index base (multi-chunk / multi-GPU draws)
@@ -571,6 +579,8 @@ def test_splat_from_the_octrees_sorted_records_is_the_same_frame(T, oracle, seed
     ptr = T.context.ptr
     T._lib.check(T.lib().treee_splat_dev(ctx.handle, ptr(d_pts), None, len(pts), ptr(view), ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h, ptr(pa), 0, 1000, None, None))
     T._lib.check(T.lib().treee_splat_octree_dev(ctx.handle, oc._h, None, ptr(view), ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h, ptr(pb), 0, 1000, None, None))
+    assert torch.equal(pa, pb)
+    T._lib.check(T.lib().treee_splat_knn_dev(ctx.handle, tree._h, None, ptr(view), ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h, ptr(pb), 0, 1000, None, None))
     assert torch.equal(pa, pb)
 
 
@@ -800,6 +810,7 @@ def test_full_size_15m_splat_bit_exact(T, oracle):
 
     cloud, prop = T.PointCloud(d_pts), T.PointCloudProperty(d_seg)
     oc = T.Octree(d_pts)
+    tree = T.KDTree.from_octree(oc)
     for tf in (T.translation(0.0, 0.0, 100.0), T.rotation_x(-np.pi / 2) @ T.translation(0.0, 0.0, 300.0)):
         view = T.view_from_transform(tf.astype(np.float32))
         depth, ids = cloud.render(prop, view, proj, env, w, h)
@@ -809,6 +820,8 @@ def test_full_size_15m_splat_bit_exact(T, oracle):
         assert int((rd < 1.0).sum()) > 50_000
         d2, i2 = cloud.render(prop, view, proj, env, w, h, octree=oc)  # drawn from the octree's sorted records: the same frame
         assert torch.equal(d2.view(torch.int32), depth.view(torch.int32)) and torch.equal(i2, ids)
+        d3, i3 = cloud.render(prop, view, proj, env, w, h, knn=tree)  # ... and from the kNN structure's, in Hilbert order (what bench.py draws)
+        assert torch.equal(d3.view(torch.int32), depth.view(torch.int32)) and torch.equal(i3, ids)
 
 
 def test_config0_uniform_1m_knn_and_curve_vs_reference_kdtree(T, oracle):

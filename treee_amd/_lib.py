@@ -102,6 +102,7 @@ SYMBOLS = {
     "treee_splat": (_i32, [_vp, _vp, _u64, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _vp, _vp]),
     "treee_splat_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _vp, _i32, _u32, _vp, _vp]),
     "treee_splat_octree_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _vp, _i32, _u32, _vp, _vp]),
+    "treee_splat_knn_dev": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _vp, _i32, _u32, _vp, _vp]),
     "treee_splat_resolve_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _u32, _vp, _vp]),
     "treee_perspective": (_i32, [_f32, _f32, _f32, _f32, _vp]),
     "treee_eye_dome_dev": (_i32, [_vp, _vp, _u32, _u32, _f32, _vp]),

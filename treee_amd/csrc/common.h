@@ -317,6 +317,9 @@ struct SortedCloud {
 };
 // the sorted cloud of an octree can be shared with a kNN structure (one sort, two consumers)
 std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o);
+// the records a kNN structure holds in ITS order (Hilbert index of the cell, index), the number of points it was built from,
+// and whether it is a segmented structure (records padded with (NaN, NaN, NaN, ~0u)) -- knn.hip
+std::shared_ptr<SortedCloud> knn_sorted_cloud(const treee_knn *t, uint64_t *n_points, bool *segmented);
 // hilbert_order: sort by the Hilbert index of the cell instead of its Morton key (a kNN structure's own cloud; out->hilbert)
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner,
                            float size, SortedCloud *out, bool fork_after_sort = false, bool hilbert_order = false);

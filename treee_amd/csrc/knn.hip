@@ -2059,6 +2059,11 @@ int32_t treee_knn_build_segments_dev(treee_ctx *ctx, const float *d_xyz, const u
 
 } // extern "C"
 namespace treee {
+std::shared_ptr<SortedCloud> knn_sorted_cloud(const treee_knn *t, uint64_t *n_points, bool *segmented) {
+	*n_points = t->n_points;
+	*segmented = t->segmented;
+	return t->sc;
+}
 int32_t knn_build_segments_cube(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_segment, uint64_t n, uint32_t n_segments, const float cube[4],
                                 treee_knn **out) {
 	*out = nullptr;

@@ -100,6 +100,7 @@ template <bool REC> __device__ __forceinline__ bool load_point(const void *__res
 		const float4 p = ((const float4 *)pts)[i];
 		x = p.x, y = p.y, z = p.z;
 		orig = __float_as_uint(p.w);
+		if (orig == 0xFFFFFFFFu) return false; // a padding record of a segmented kNN structure (treee_splat_knn_dev): no point, no value
 	} else {
 		const float *xyz = (const float *)pts;
 		x = xyz[3ull * i + 0], y = xyz[3ull * i + 1], z = xyz[3ull * i + 2];
@@ -409,6 +410,21 @@ int32_t treee_splat_octree_dev(treee_ctx *ctx, const treee_octree *o, const uint
 	TREEE_TRY(use_begin(ctx, sc->owner, &sc->sync));
 	const int32_t rc = splat_any(ctx, sc->d_sorted, true, d_value, sc->n, octree_is_shard(o) ? 0xFFFFFFFEull - index_base : sc->n, view, proj, scale, vmin, vmax,
 	                             w, h, d_packed, accumulate, index_base, d_depth, d_id);
+	const int32_t e = use_end(ctx, sc->owner, &sc->sync);
+	return rc != TREEE_OK ? rc : e;
+}
+
+int32_t treee_splat_knn_dev(treee_ctx *ctx, const treee_knn *t, const uint32_t *d_value, const float view[16], const float proj[16], float scale,
+                            uint32_t vmin, uint32_t vmax, uint32_t w, uint32_t h, uint64_t *d_packed, int32_t accumulate, uint32_t index_base,
+                            float *d_depth, uint32_t *d_id) {
+	if (!ctx || !t || !view || !proj) return set_err(TREEE_ERR_INVALID, "treee_splat_knn_dev: null argument");
+	uint64_t n_points = 0;
+	bool segmented = false;
+	std::shared_ptr<SortedCloud> sc = knn_sorted_cloud(t, &n_points, &segmented);
+	if (sc->device != ctx->device) return set_err(TREEE_ERR_INVALID, "treee_splat_knn_dev: context of another device");
+	TREEE_TRY(use_begin(ctx, sc->owner, &sc->sync));
+	const int32_t rc = splat_any(ctx, sc->d_sorted, true, d_value, sc->n, n_points, view, proj, scale, vmin, vmax, w, h, d_packed, accumulate, index_base, d_depth,
+	                             d_id);
 	const int32_t e = use_end(ctx, sc->owner, &sc->sync);
 	return rc != TREEE_OK ? rc : e;
 }

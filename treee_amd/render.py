@@ -72,9 +72,10 @@ class PointCloud:
         self.buffer = dev_f32(vertices, 3) if is_device(vertices) else host_f32(vertices, 3)
         self.instances = int(self.buffer.shape[0])
 
-    def render(self, property, view, proj, environment, width, height, ctx=None, octree=None):
+    def render(self, property, view, proj, environment, width, height, ctx=None, octree=None, knn=None):
         """one draw of all instances; returns (depth[h,w] f32, id[h,w] u32).  `octree` (an Octree built from these very
-        vertices): draw from its Morton-sorted records instead (treee_splat_octree_dev) -- the same frame, bit for bit."""
+        vertices): draw from its Morton-sorted records instead (treee_splat_octree_dev); `knn` (a KDTree built from them): from the
+        records it holds in Hilbert order (treee_splat_knn_dev) -- the same frame, bit for bit, either way."""
         if property.length != 0:
             assert property.length == self.instances, f"{property.length} {self.instances}"  # point_cloud.rs:161-167
         view = host_f32(view).reshape(16)
@@ -86,6 +87,11 @@ class PointCloud:
             c = ctx or default_context(self.buffer.device)
             depth = torch.empty((height, width), dtype=torch.float32, device=self.buffer.device)
             ids = torch.empty((height, width), dtype=torch.int32, device=self.buffer.device)
+            if knn is not None:
+                assert len(knn) == self.instances
+                _lib.check(_lib.lib().treee_splat_knn_dev(c.handle, knn._h, ptr(property.data), ptr(view), ptr(proj), env.scale, env.min, env.max,
+                                                          width, height, None, 0, 0, ptr(depth), ptr(ids)))
+                return depth, ids
             if octree is not None:
                 assert octree.n_points == self.instances
                 _lib.check(_lib.lib().treee_splat_octree_dev(c.handle, octree._h, ptr(property.data), ptr(view), ptr(proj), env.scale, env.min, env.max,
