@@ -474,6 +474,21 @@ int main(int argc, char **argv) {
 		if (fread(c.pts.data(), 12, c.pts.size(), f) != c.pts.size()) return 1;
 		fclose(f);
 	}
+	const uint32_t kd_block = argc > 3 ? (uint32_t)atoi(argv[3]) : 0;
+	if (kd_block >= 128) {
+		// buckets as the leaves of a small k-d tree over every block of kd_block curve-consecutive points instead of runs of the curve
+		struct R { static void split(P3 *p, size_t n) {
+			if (n <= 64) return;
+			Box b = box_of(p, (int)n);
+			int ax = 0; float ext = -1;
+			for (int a = 0; a < 3; ++a) if (b.hi[a] - b.lo[a] > ext) { ext = b.hi[a] - b.lo[a]; ax = a; }
+			const size_t half = (n / 2 + 63) / 64 * 64 == n ? n / 2 : (n / 128) * 64; // whole buckets on the left
+			const size_t h = half ? half : 64;
+			std::nth_element(p, p + h, p + n, [ax](const P3 &x, const P3 &y) { return (&x.x)[ax] < (&y.x)[ax]; });
+			split(p, h); split(p + h, n - h);
+		} };
+		for (size_t i = 0; i + 64 <= c.pts.size(); i += kd_block) R::split(&c.pts[i], std::min<size_t>(kd_block, c.pts.size() - i));
+	}
 	c.build();
 	const uint32_t stride = argc > 2 ? (uint32_t)atoi(argv[2]) : 4;
 	struct Variant {
