@@ -1365,7 +1365,10 @@ def _shard_worker(rank, world, port, out_dir, backend="gloo"):
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    # gloo: both ranks share GPU 0 and the collectives are staged through the host; nccl (= RCCL): one GPU per rank
+    # gloo: both ranks share GPU 0 and the collectives are staged through the host; nccl (= RCCL): one GPU per rank;
+    # double: as gloo, but the library's RCCL transport runs against tests/cpp/rccl_peer_double.cpp (a peer on a one-GPU box)
+    if backend == "double":
+        os.environ["TREEE_RCCL_LIB"] = _peer_double()
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
     if backend == "nccl":
@@ -1380,14 +1383,18 @@ def _shard_worker(rank, world, port, out_dir, backend="gloo"):
     ctx = T.default_context(dev)
     pts, _ = synth.forest_cloud_torch(n, dev, plot=plot, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, plot))
     bounds = D.tile_bounds(rank, world, plot)
-    cloud = D.GhostExchanger(pts, bounds, halo, rank, world, ctx=ctx).exchange(halo)
+    # (a gloo group's default is the host transport; the double serves the library's RCCL transport: ncclAllGather of the blocks)
+    ex = D.GhostExchanger(pts, bounds, halo, rank, world, ctx=ctx, comm=D.Comm.rccl() if backend == "double" else None)
+    assert ex.comm.is_rccl == (backend != "gloo") and ex.comm.world == world
+    cloud = ex.exchange(halo)
     tree = T.KDTree.new(cloud, ctx)
     d, _, c = tree.self_neighbors_dev(31)
     ok = D.halo_is_sufficient(pts, d[:n, 30], bounds, halo, rank, world)
     curve = tree.curvature_dev(31, n_own=n)
     # the same structure WITHOUT a second sort of the tile (bench.py's N > 1 step): the sharded octree holds the own points in
     # Morton order of the common cube, the ghosts are merged in by the structure's own (Hilbert) sort (treee_knn_from_shard_dev)
-    comm = D.Comm.host() if backend == "gloo" else D.Comm.auto()
+    comm = D.Comm.host() if backend == "gloo" else D.Comm.rccl() if backend == "double" else D.Comm.auto()
+    assert comm.is_rccl == (backend != "gloo") and comm.world == world
     so = T.ShardedOctree(pts, comm, ctx=ctx)
     tree2 = T.KDTree.from_shard(so, cloud[n:], ctx)
     assert len(tree2) == cloud.shape[0]
@@ -1437,7 +1444,16 @@ def _rccl_available():
     return torch.cuda.device_count() >= 2
 
 
-@pytest.mark.parametrize("backend", ["gloo", pytest.param("nccl", marks=pytest.mark.skipif("not _rccl_available()", reason="RCCL needs two GPUs (the gpurun box has one)"))])
+def _peer_double():
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as G
+
+    return G.build_rccl_peer_double()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "double", pytest.param("nccl", marks=pytest.mark.skipif("not _rccl_available()", reason="RCCL needs two GPUs (the gpurun box has one)"))])
 def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path, backend):
     """with a sufficient (verified) halo, every own point of a shard finds exactly the neighbours it finds
     when one GPU holds the whole cloud -- distances bit for bit; curvature within the tie tolerance.  `nccl` runs the
@@ -1451,6 +1467,8 @@ def test_two_shards_reproduce_the_single_gpu_neighbours(T, tmp_path, backend):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    if backend == "double":
+        _peer_double()  # built once, here, not by the two ranks at the same time
     mp.spawn(_shard_worker, args=(2, port, str(tmp_path), backend), nprocs=2, join=True)
     res = [torch.load(os.path.join(tmp_path, f"shard{r}.pt")) for r in range(2)]
     whole = torch.cat([r["pts"] for r in res]).cuda()
@@ -1541,13 +1559,15 @@ def test_sharded_octree_of_one_rank_is_the_octree(T, oracle, n, top_level, leaf_
     comm.close()
 
 
-def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
+def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level, transport="host"):
     import os
 
     import torch
     import torch.distributed as dist
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if transport == "double":  # the library's RCCL transport against a peer that checks what it is sent (tests/cpp/rccl_peer_double.cpp)
+        os.environ["TREEE_RCCL_LIB"] = _peer_double()
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import treee_amd as T
@@ -1582,7 +1602,8 @@ def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
     else:
         pts, _ = synth.forest_cloud(200_000, plot=30.0, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, 30.0))
     pts = np.ascontiguousarray(pts, np.float32)
-    comm = D.Comm.host()
+    comm = D.Comm.rccl() if transport == "double" else D.Comm.host()
+    assert comm.is_rccl == (transport == "double") and comm.world == world
     cube = dict(corner=np.zeros(3, np.float32), size=4096.0) if layout == "one_cell" else {}
     so = T.ShardedOctree(torch.from_numpy(pts).cuda(), comm, leaf_cap=64, lod_cap=32, top_level=top_level, **cube)
     # the frame of the rank's own points, min-reduced through the same communicator (treee_frame_reduce_min_dev)
@@ -1604,13 +1625,20 @@ def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,layout,top_level", [(2, "tiles", 0), (2, "interleaved", 4), (3, "skewed", 2), (3, "interleaved", 5), (2, "one_empty", 3),
-                                                    (3, "one_cell", 2), (2, "full_size", 0), (4, "fuzz1", 1), (3, "fuzz2", 3), (4, "fuzz3", 6), (2, "fuzz4", 4)])
-def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_path, world, layout, top_level):
+@pytest.mark.parametrize("world,layout,top_level,transport",
+                         [(2, "tiles", 0, "host"), (2, "interleaved", 4, "host"), (3, "skewed", 2, "host"), (3, "interleaved", 5, "host"), (2, "one_empty", 3, "host"),
+                          (3, "one_cell", 2, "host"), (2, "full_size", 0, "host"), (4, "fuzz1", 1, "host"), (3, "fuzz2", 3, "host"), (4, "fuzz3", 6, "host"),
+                          (2, "fuzz4", 4, "host"), (2, "tiles", 0, "double"), (3, "interleaved", 5, "double"), (2, "one_empty", 3, "double"),
+                          (3, "one_cell", 2, "double"), (4, "fuzz1", 1, "double"), (3, "fuzz2", 3, "double"), (2, "full_size", 0, "double")])
+def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_path, world, layout, top_level, transport):
     """(world <= 4: the GPU box allows six processes on its card and this test process is one of them.)
     SURVEY 8 E / BASELINE configs[3]: the ranks (sharing this GPU, host transport over gloo) build
     their pieces of ONE octree -- common cube, Morton-prefix ownership, one all-to-all, replicated top, global numbering --
-    and the pieces are, bit for bit, the octree one GPU builds of the concatenated cloud."""
+    and the pieces are, bit for bit, the octree one GPU builds of the concatenated cloud.
+    transport "double": the same through the library's RCCL transport (RcclComm, csrc/comm.cpp: grouped send / receive with
+    its offsets, the in-place MIN all-reduce, the unique-id hand-shake of Comm.rccl) with peers -- real RCCL refuses two ranks
+    on one device, so the ten entry points are served by tests/cpp/rccl_peer_double.cpp, which moves the bytes through shared
+    memory and fails on a receive whose size is not its send's, an unmatched send, or a zero-byte call."""
     import socket
 
     import torch
@@ -1619,7 +1647,9 @@ def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_sharded_octree_worker, args=(world, port, str(tmp_path), layout, top_level), nprocs=world, join=True)
+    if transport == "double":
+        _peer_double()  # built once, here, not by the ranks at the same time
+    mp.spawn(_sharded_octree_worker, args=(world, port, str(tmp_path), layout, top_level, transport), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"so{r}.pt"), weights_only=False) for r in range(world)]
     whole = np.concatenate([r["pts"] for r in res])
     corner, size = (np.zeros(3, np.float32), 4096.0) if layout == "one_cell" else cube_of(whole)
@@ -1642,6 +1672,60 @@ def test_sharded_octree_pieces_assemble_to_the_single_gpu_octree(T, oracle, tmp_
                                          0.3, 0, 0xFFFFFFFF, w, h, T.context.ptr(packed), 0, 0, None, None))
     for r in res:
         assert torch.equal(r["packed"], packed.cpu())
+
+
+def _peer_double_misuse_worker(rank, world, out_dir, uid_path):
+    """two ranks drive the double directly: a matched exchange moves the bytes, a receive shorter than its send is refused"""
+    import ctypes as C
+    import time
+
+    import torch
+
+    torch.cuda.set_device(0)
+    class Uid(C.Structure):  # ncclUniqueId, passed by value
+        _fields_ = [("internal", C.c_char * 128)]
+
+    L = C.CDLL(_peer_double())
+    uid = Uid()
+    if rank == 0:
+        assert L.ncclGetUniqueId(C.byref(uid)) == 0
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(bytes(uid))
+        os.replace(uid_path + ".tmp", uid_path)
+    else:
+        while not os.path.exists(uid_path):
+            time.sleep(0.01)
+        C.memmove(C.byref(uid), open(uid_path, "rb").read(), 128)
+    L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+    for f in (L.ncclSend, L.ncclRecv):
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    comm = C.c_void_p()
+    assert L.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    U8, peer = 1, 1 - rank  # ncclUint8
+    send = torch.full((1000,), 10 + rank, dtype=torch.uint8, device="cuda")
+    recv = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    L.ncclGroupStart()
+    assert L.ncclSend(send.data_ptr(), 1000, U8, peer, comm, None) == 0 and L.ncclRecv(recv.data_ptr(), 1000, U8, peer, comm, None) == 0
+    assert L.ncclGroupEnd() == 0 and bool((recv == 10 + peer).all())
+    # rank 1 now expects half of what rank 0 sends: real RCCL would truncate or hang; the double says so on the receiving rank
+    L.ncclGroupStart()
+    L.ncclSend(send.data_ptr(), 1000, U8, peer, comm, None)
+    L.ncclRecv(recv.data_ptr(), 500 if rank == 1 else 1000, U8, peer, comm, None)
+    rc = L.ncclGroupEnd()
+    open(os.path.join(out_dir, f"rc{rank}"), "w").write(str(rc))
+    L.ncclCommDestroy(comm)
+
+
+def test_peer_double_refuses_what_real_rccl_would_corrupt(T, tmp_path):
+    """the double that stands in for librccl in the tests above is not vacuous: a matched grouped exchange moves the bytes, and
+    a receive whose size is not its send's fails (on the receiving rank at once, on the peer at its next barrier)"""
+    import torch.multiprocessing as mp
+
+    _peer_double()
+    mp.spawn(_peer_double_misuse_worker, args=(2, str(tmp_path), os.path.join(tmp_path, "uid")), nprocs=2, join=True)
+    rc = [int(open(os.path.join(tmp_path, f"rc{r}")).read()) for r in range(2)]
+    assert rc[1] != 0 and rc[0] != 0
 
 
 def test_rccl_transport_with_one_rank(T, oracle):
