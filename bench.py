@@ -747,7 +747,9 @@ def committed_counters(points):
         if c.get("knn_hip_sha16") == sha and c.get("points_per_launch", 15_000_000) == points:
             out["valu_busy"] = round(float(c.get("waves_per_simd", 3)) * c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"], 3)
             used["valu_busy"] = os.path.basename(cp)
-        out["counters_from"] = used or f"stale: newest committed summaries ({os.path.basename(tp)}, {os.path.basename(cp)}) were not measured with this csrc/knn.hip ({sha})"
+        why = (f"were not measured with this csrc/knn.hip ({sha})" if t.get("knn_hip_sha16") != sha or c.get("knn_hip_sha16") != sha
+               else f"describe launches of {t['points_per_launch']} points, this run's have {points}")
+        out["counters_from"] = used or f"stale: newest committed summaries ({os.path.basename(tp)}, {os.path.basename(cp)}) {why}"
     except Exception as e:
         out["counters_from"] = f"unavailable: {type(e).__name__}"
     return out
