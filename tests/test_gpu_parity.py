@@ -224,6 +224,70 @@ def test_knn_structure_from_an_octree_orders_cells_like_the_point_sort(T):
         oc.close()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_block_sorted_hilbert_order_on_ragged_clouds(T, seed):
+    """hilbert_order_by_blocks (knn.hip, round 4) sorts tiles of whole 2^-7 blocks in registers and LDS; which tiles exist, how
+    full they are and which of the two capacities they take depends on the cloud.  Seeded clouds of 1.0-1.6 M points must give
+    the structure built from the raw points, neighbour list for neighbour list, index for index:
+    kinds 0-5 take the block path with ragged tiles (density gradients, a bumpy sheet, clusters, sheet + box + filaments, a sparse box
+    with blocks of 1 600-1 950 points = the 4 096-key tiles) or sit just below its threshold (kind 5: blocks of one or two points);
+    kinds 6-9 are what the path must hand back to the point sort (blocks of > 2 048 points beside blocks of one, cells full of
+    duplicates, a far outlier that squeezes the cloud into a few blocks, a very dense ball) -- TREEE_KNN_TRACE=1 shows which."""
+    import torch
+
+    rng = np.random.default_rng(7000 + seed)
+    kind = seed % 10
+    # (the block path starts at 2^20 points: exactly there, one past, and -- kind 5 -- just below, where the point sort stays)
+    n = [1_048_576, 1_048_577, 1_300_000, 1_600_000, 1_200_000, 1_000_000, 1_300_000, 1_600_000, 1_000_000, 1_048_577][kind] + 123_457 * (seed // 10)
+    if kind == 0:  # density falls by two orders of magnitude along x and z
+        pts = np.stack([rng.random(n) ** 2.5, rng.random(n) * 0.3, rng.random(n) ** 1.7], 1) * 90
+    elif kind == 1:  # a bumpy sheet 2 mm thick: ~90 points per occupied block, whole block rows empty
+        x, z = rng.random(n) * 120, rng.random(n) * 120
+        pts = np.stack([x, 4 * np.sin(x / 9) * np.cos(z / 13) + rng.standard_normal(n) * 0.002, z], 1)
+    elif kind == 2:  # 300 clusters a few blocks wide
+        centres, sigma = rng.random((300, 3)) * 100, rng.uniform(1.2, 5.0, 300)
+        which = rng.integers(0, 300, n)
+        pts = centres[which] + rng.standard_normal((n, 3)) * sigma[which, None]
+    elif kind == 3:  # ground sheet + uniform box + vertical filaments ("stems")
+        m = n // 3
+        sheet = np.stack([rng.random(m) * 80, rng.standard_normal(m) * 0.01, rng.random(m) * 80], 1)
+        box = rng.random((m, 3)) * np.array([80, 25, 80])
+        stems = rng.integers(0, 400, n - 2 * m)
+        base = rng.random((400, 2)) * 80
+        fil = np.stack([base[stems, 0] + rng.standard_normal(n - 2 * m) * 0.08, rng.random(n - 2 * m) * 20, base[stems, 1] + rng.standard_normal(n - 2 * m) * 0.08], 1)
+        pts = np.concatenate([sheet, box, fil])[rng.permutation(n)]
+    elif kind == 4:  # a sparse box in which 60 blocks hold 1 600-1 950 points each: tiles of the larger capacity (4 096 keys)
+        pts = rng.random((n, 3)) * 100
+        pts[0], pts[1] = (0.0, 0.0, 0.0), (100.0, 100.0, 100.0)  # the cube: blocks of 100 / 128
+        edge, o = 100.0 / 128.0, 2
+        for cell in rng.integers(5, 120, (60, 3)):
+            m = int(rng.integers(1600, 1950))
+            pts[o : o + m] = (cell + 0.05 + 0.9 * rng.random((m, 3))) * edge
+            o += m
+    elif kind == 5:  # a cloud of almost-empty blocks
+        pts = rng.random((n, 3)) * np.array([100, 100, 100])
+    elif kind == 6:  # clusters whose spread spans three orders of magnitude
+        centres, sigma = rng.random((40, 3)) * 100, 10.0 ** rng.uniform(-2.0, 1.0, 40)
+        which = rng.integers(0, 40, n)
+        pts = centres[which] + rng.standard_normal((n, 3)) * sigma[which, None]
+    elif kind == 7:  # 5 cm lattice: duplicates in every cell, equal distances everywhere
+        pts = np.round(rng.random((n, 3)) * np.array([60, 4, 60]) / 0.05) * 0.05
+    elif kind == 8:  # an outlier stretches the cube
+        pts = rng.random((n, 3)) * 20
+        pts[-1] = (4000.0, -2500.0, 9000.0)
+    else:  # uniform box with one very dense ball
+        pts = rng.random((n, 3)) * np.array([150, 30, 150])
+        pts[: n // 5] = (70.0, 10.0, 70.0) + rng.standard_normal((n // 5, 3)) * 0.3
+    d_pts = torch.from_numpy(np.ascontiguousarray(pts, np.float32)).cuda()
+    oc = T.Octree(d_pts)
+    a, b = T.KDTree.from_octree(oc), T.KDTree.new(d_pts)
+    for k in (31, 5):
+        (da, ia, ca), (db, ib, cb) = a.self_neighbors_dev(k), b.self_neighbors_dev(k)
+        assert torch.equal(da.view(torch.int32), db.view(torch.int32)) and torch.equal(ia, ib) and torch.equal(ca, cb), (seed, k)
+    for h in (a, b, oc):
+        h.close()
+
+
 # ---------------------------------------------------------------- A5 curvature
 def same_f32(a, b):
     """bit-identical f32 arrays; NaN matches NaN (0/0 has the sign bit set on x86 and clear on gfx950)"""
