@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void k_task_starts(const uint32_t *__restrict_
 
 // ---- Tree::new / insert / statistics for one (segment, slice) per wave -----------------------------------------
 constexpr uint32_t HULL_LDS = 128; // hull vertices kept in LDS per wave; a larger hull moves to the task's slot in HBM
+constexpr uint32_t EDGE_MODE_POINTS = 64; // the first points of a slice are inserted one by one, an edge per lane (slice_hull_wave)
 
 struct P2 {
 	float x, y;
@@ -244,13 +245,59 @@ __device__ __forceinline__ bool edge_outside(P2 a, P2 nrm, P2 p) {
 
 // Slices of BIG_TASK points or more (the ground of a plot holds hundreds of thousands per slice) get a workgroup of 16
 // waves instead of one wave: 1024 points are tested per round, everything else is the same algorithm.
-constexpr uint32_t BIG_TASK = 2048, BIG_THREADS = 1024, BIG_LDS = 2048, BIG_PPT = 1;
+#ifndef TREEE_BIG_PPT
+#define TREEE_BIG_PPT 1
+#endif
+#ifndef TREEE_BIG_ONE_BY_ONE
+#define TREEE_BIG_ONE_BY_ONE 512
+#endif
+constexpr uint32_t BIG_TASK = 2048, BIG_THREADS = 1024, BIG_LDS = 2048, BIG_PPT = TREEE_BIG_PPT, BIG_ONE_BY_ONE = TREEE_BIG_ONE_BY_ONE;
 __global__ __launch_bounds__(256) void k_big_tasks(const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n, uint32_t *__restrict__ big_list,
                                                     uint32_t *__restrict__ big_count) {
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	if (t >= n_tasks) return;
 	const uint32_t count = (t + 1u < n_tasks ? task_start[t + 1u] : n) - task_start[t];
 	if (count >= BIG_TASK) big_list[atomicAdd(big_count, 1u)] = t; // (any order: the tasks are independent)
+}
+
+// The first points of a slice nearly all change the hull (a tree's slice holds ~20 points and ~10 of them do; a ground slice of
+// 300 000 makes most of its ~300 changes in its first few thousand), and in the batch loops below every change costs a scan of
+// the whole hull by every lane.  So the first points go the other way round while the hull has at most 64 edges: ONE EDGE PER
+// LANE of one wave, the points one after the other in slice order -- one edge test per point, and the scan of
+// segmenting.rs:356-370 (`start` = the last edge that is outside after an edge that is not, `end` = the last that is not
+// after one that is, the last edge preceding edge 0) is bit arithmetic on the ballot.  Same hull, vertex for vertex: the order of
+// the insertions is the slice's either way.  Takes the pending points of one 64-point batch (lane = position in the batch);
+// returns with `pending` still set for the points it did not get to (the hull outgrew 64 edges).
+template <class Splice, class NewTree>
+__device__ __forceinline__ void insert_one_by_one(P2 *&H, P2 *&N, uint32_t &m, const P2 p, bool &pending, const uint32_t lane, Splice &&splice,
+                                                  NewTree &&new_tree) {
+	uint64_t pm = __ballot(pending);
+	P2 hv = {0.0f, 0.0f}, nv = {0.0f, 0.0f};
+	bool fresh = false; // hv / nv hold the current hull's vertex `lane` and the normal of the edge that starts there
+	while (pm != 0ull && m <= 64u) {
+		const int f = __builtin_ctzll(pm);
+		pm &= pm - 1ull;
+		const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.x), f)), py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p.y), f));
+		pending = pending && (int)lane > f;
+		if (m == 0) { // Tree::new (segmenting.rs:258-269)
+			new_tree(px, py);
+			continue;
+		}
+		if (!fresh) {
+			if (lane < m) {
+				hv = H[lane];
+				nv = N[lane];
+			}
+			fresh = true;
+		}
+		const uint64_t outside = __ballot(lane < m && edge_outside(hv, nv, P2{px, py}));
+		const uint64_t all = m == 64u ? ~0ull : (1ull << m) - 1ull;
+		const uint64_t before = ((outside << 1) | (outside >> (m - 1u))) & all; // bit j = edge j - 1 (edge m - 1 for j = 0)
+		const uint64_t starts = outside & ~before, ends = ~outside & before;
+		if (starts == 0ull || ends == 0ull) continue; // inside (or outside every edge): Tree::insert returns without a change
+		splice(63u - (uint32_t)__builtin_clzll(starts), 63u - (uint32_t)__builtin_clzll(ends), px, py);
+		fresh = false;
+	}
 }
 
 // one wave per task.  `cls` (optional): only points with cls[orig] == want take part (calculations.rs:299-301).
@@ -281,6 +328,61 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 		sync();
 	};
 
+	// splice (segmenting.rs:374-380) of the point (px, py) between the edges s0 and e0, then the normals of the new hull
+	auto splice = [&](uint32_t s0, uint32_t e0, float px, float py) __attribute__((always_inline)) {
+		// splice (segmenting.rs:374-380), cooperative.  Lanes move in lockstep: every lane reads its element before any
+		// lane writes, and the chunks run in the direction that never overwrites an unread source.
+		// (new size first: a hull that outgrows its LDS copy moves to the task's HBM slot BEFORE anything is written --
+		// the append case e0 == 0, s0 == m - 1 of the first branch grows the hull by one too)
+		const uint32_t new_m = e0 < s0 ? s0 - e0 + 2u : s0 + 2u + (m - e0);
+		if (new_m > cap) {
+			for (uint32_t c = 0; c < m; c += 64u)
+				if (c + lane < m) big[c + lane] = H[c + lane];
+			H = big;
+			N = big + (count + 2u);
+			cap = 0xFFFFFFFFu;
+			sync();
+		}
+		if (e0 < s0) { // H' = H[e0 ..= s0] + [point]
+			const uint32_t keep = s0 - e0 + 1u;
+			if (e0 > 0u)
+				for (uint32_t c = 0; c < keep; c += 64u) {
+					const uint32_t k = c + lane;
+					P2 v = {0.0f, 0.0f};
+					if (k < keep) v = H[e0 + k];
+					__builtin_amdgcn_wave_barrier();
+					if (k < keep) H[k] = v;
+					sync();
+				}
+			if (lane == 0) H[keep] = P2{px, py};
+		} else { // H' = H[0 ..= s0] + [point] + H[e0 .. m)
+			const uint32_t tail = m - e0, dst = s0 + 2u;
+			if (dst < e0) { // shrink: shift the tail left, ascending
+				for (uint32_t c = 0; c < tail; c += 64u) {
+					const uint32_t k = c + lane;
+					P2 v = {0.0f, 0.0f};
+					if (k < tail) v = H[e0 + k];
+					__builtin_amdgcn_wave_barrier();
+					if (k < tail) H[dst + k] = v;
+					sync();
+				}
+			} else if (dst > e0) { // grow by one: shift the tail right, descending
+				for (uint32_t c = (tail + 63u) / 64u; c-- > 0u;) {
+					const uint32_t k = c * 64u + lane;
+					P2 v = {0.0f, 0.0f};
+					if (k < tail) v = H[e0 + k];
+					__builtin_amdgcn_wave_barrier();
+					if (k < tail) H[dst + k] = v;
+					sync();
+				}
+			}
+			if (lane == 0) H[s0 + 1u] = P2{px, py};
+		}
+		m = new_m;
+		sync();
+		normals();
+	};
+
 	for (uint32_t base = 0; base < count; base += 64u) {
 		const uint32_t i = base + lane;
 		bool pending = i < count;
@@ -291,6 +393,18 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 			p.y = xyz[3ull * o + 2];
 			if (cls) pending = cls[o] == want;
 		}
+		// (the first batch: an edge per lane, see insert_one_by_one)
+		if (base < EDGE_MODE_POINTS)
+			insert_one_by_one(H, N, m, p, pending, lane, splice, [&](float px, float py) __attribute__((always_inline)) {
+				if (lane == 0) {
+					H[0] = P2{px, py};
+					H[1] = P2{px + 0.1f, py};
+					H[2] = P2{px, py + 0.1f};
+				}
+				m = 3;
+				sync();
+				normals();
+			});
 		for (;;) {
 			uint64_t pm = __ballot(pending);
 			if (!pm) break;
@@ -352,58 +466,8 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 			const int f = __builtin_ctzll(mm); // the first one in slice order: everything before it was a no-op
 			const uint32_t s0 = (uint32_t)__shfl((int)st, f, 64), e0 = (uint32_t)__shfl((int)en, f, 64);
 			const float px = __shfl(p.x, f, 64), py = __shfl(p.y, f, 64);
-			// splice (segmenting.rs:374-380), cooperative.  Lanes move in lockstep: every lane reads its element before any
-			// lane writes, and the chunks run in the direction that never overwrites an unread source.
-			// (new size first: a hull that outgrows its LDS copy moves to the task's HBM slot BEFORE anything is written --
-			// the append case e0 == 0, s0 == m - 1 of the first branch grows the hull by one too)
-			const uint32_t new_m = e0 < s0 ? s0 - e0 + 2u : s0 + 2u + (m - e0);
-			if (new_m > cap) {
-				for (uint32_t c = 0; c < m; c += 64u)
-					if (c + lane < m) big[c + lane] = H[c + lane];
-				H = big;
-				N = big + (count + 2u);
-				cap = 0xFFFFFFFFu;
-				sync();
-			}
-			if (e0 < s0) { // H' = H[e0 ..= s0] + [point]
-				const uint32_t keep = s0 - e0 + 1u;
-				if (e0 > 0u)
-					for (uint32_t c = 0; c < keep; c += 64u) {
-						const uint32_t k = c + lane;
-						P2 v = {0.0f, 0.0f};
-						if (k < keep) v = H[e0 + k];
-						__builtin_amdgcn_wave_barrier();
-						if (k < keep) H[k] = v;
-						sync();
-					}
-				if (lane == 0) H[keep] = P2{px, py};
-			} else { // H' = H[0 ..= s0] + [point] + H[e0 .. m)
-				const uint32_t tail = m - e0, dst = s0 + 2u;
-				if (dst < e0) { // shrink: shift the tail left, ascending
-					for (uint32_t c = 0; c < tail; c += 64u) {
-						const uint32_t k = c + lane;
-						P2 v = {0.0f, 0.0f};
-						if (k < tail) v = H[e0 + k];
-						__builtin_amdgcn_wave_barrier();
-						if (k < tail) H[dst + k] = v;
-						sync();
-					}
-				} else if (dst > e0) { // grow by one: shift the tail right, descending
-					for (uint32_t c = (tail + 63u) / 64u; c-- > 0u;) {
-						const uint32_t k = c * 64u + lane;
-						P2 v = {0.0f, 0.0f};
-						if (k < tail) v = H[e0 + k];
-						__builtin_amdgcn_wave_barrier();
-						if (k < tail) H[dst + k] = v;
-						sync();
-					}
-				}
-				if (lane == 0) H[s0 + 1u] = P2{px, py};
-			}
-			m = new_m;
+			splice(s0, e0, px, py);
 			pending = pending && (int)lane > f;
-			sync();
-			normals();
 		}
 	}
 	// Tree::statistics().area = centroid(points).1 (segmenting.rs:526-545): triangle fan around points[0], summed in order
@@ -458,9 +522,70 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS entri
 			__syncthreads();
 		}
 	};
+	// The first BIG_ONE_BY_ONE points: wave 0 alone, an edge per lane (insert_one_by_one) -- most of a long slice's changes
+	// happen there, and a change in the rounds below costs the whole workgroup a scan of the hull and seven barriers
+	__shared__ uint32_t s_m, s_done;
+	if (tid < 64u) {
+		uint32_t done = 0;
+		auto sync = [&]() __attribute__((always_inline)) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+		};
+		auto wave_normals = [&]() __attribute__((always_inline)) {
+			for (uint32_t c = 0; c < m; c += 64u) {
+				const uint32_t j = c + tid;
+				if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+			}
+			sync();
+		};
+		for (uint32_t base = 0; base < count && base < BIG_ONE_BY_ONE && m <= 64u; base += 64u) {
+			const uint32_t i = base + tid;
+			bool pending = i < count;
+			P2 p = {0.0f, 0.0f};
+			if (pending) {
+				const uint32_t o = order[begin + i];
+				p.x = xyz[3ull * o + 0];
+				p.y = xyz[3ull * o + 2];
+				if (cls) pending = cls[o] == want;
+			}
+			insert_one_by_one(
+			    H, N, m, p, pending, tid,
+			    [&](uint32_t s0, uint32_t e0, float px, float py) __attribute__((always_inline)) { // m <= 64 here: one chunk, LDS
+				    const bool wraps = e0 < s0;                                                     // H' = H[e0 ..= s0] + [point]
+				    const uint32_t len = wraps ? s0 - e0 + 1u : m - e0, dst = wraps ? 0u : s0 + 2u; // else H[0 ..= s0] + [point] + H[e0 .. m)
+				    P2 v = {0.0f, 0.0f};
+				    if (tid < len) v = H[e0 + tid];
+				    __builtin_amdgcn_wave_barrier();
+				    if (tid < len && dst != e0) H[dst + tid] = v;
+				    if (tid == 0) H[wraps ? len : s0 + 1u] = P2{px, py};
+				    m = wraps ? len + 1u : dst + len;
+				    sync();
+				    wave_normals();
+			    },
+			    [&](float px, float py) __attribute__((always_inline)) {
+				    if (tid == 0) {
+					    H[0] = P2{px, py};
+					    H[1] = P2{px + 0.1f, py};
+					    H[2] = P2{px, py + 0.1f};
+				    }
+				    m = 3;
+				    sync();
+				    wave_normals();
+			    });
+			const uint64_t left = __ballot(pending); // the hull outgrew 64 edges inside this batch: the rounds below take over there
+			done = left ? base + (uint32_t)__builtin_ctzll(left) : (base + 64u < count ? base + 64u : count);
+			if (left) break;
+		}
+		if (tid == 0) {
+			s_m = m;
+			s_done = done;
+		}
+	}
+	__syncthreads();
+	m = s_m;
 	// BIG_PPT points per thread and round: an edge is read once for all of them, and a round that changes nothing -- most
 	// rounds of a long slice -- retires BIG_PPT * 1024 points.  Point r of a round (slice order) = j * BIG_THREADS + tid.
-	for (uint32_t base = 0; base < count; base += BIG_PPT * BIG_THREADS) {
+	for (uint32_t base = s_done; base < count; base += BIG_PPT * BIG_THREADS) {
 		bool pending[BIG_PPT];
 		P2 p[BIG_PPT];
 #pragma unroll
@@ -729,15 +854,27 @@ __global__ __launch_bounds__(256) void k_init_i32(int32_t *__restrict__ p, uint3
 	if (i < n) p[i] = v;
 }
 __global__ __launch_bounds__(256) void k_seg_max_expansion(const float *__restrict__ expansion, const uint32_t *__restrict__ seg, uint32_t n,
-                                                            int32_t *__restrict__ best) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n) return;
-	// max_by(total_cmp): equal keys are identical bits.  A plain read first: the stored maximum only grows, so a value that
-	// does not beat even a stale copy of it has nothing to add (3 M points of a ground segment would otherwise queue up on
-	// one word); a wave whose lanes share the segment sends one atomic
-	const uint32_t sg = seg[i];
-	const int32_t key = f2total(expansion[i]);
-	if (key <= *(volatile const int32_t *)&best[sg]) return;
+                                                            uint32_t stride, int32_t *__restrict__ best) {
+	const uint64_t i64 = (uint64_t)(blockIdx.x * 256u + threadIdx.x) * stride;
+	const uint32_t i = i64 < n ? (uint32_t)i64 : n;
+	// max_by(total_cmp): equal keys are identical bits.  The stored maximum only grows, so a value that does not beat even a
+	// stale copy of it has nothing to add -- but the half million threads resident when the kernel starts all read the
+	// initial word, and their atomics on a ground segment's ONE word are served one after the other (1.17 ms of a 15 M-point
+	// cloud's 1.3, 5.4 ms for a cloud that is one segment).  Two remedies: a wave whose lanes share the segment reduces first and
+	// sends one atomic (mixed waves -- segment borders, unsorted clouds -- keep one per lane that still beats the stored value);
+	// and the kernel runs twice, first over every `stride`-th point: a segment's expansions are its slices' (few distinct
+	// values), so the sample nearly always holds a large segment's maximum and the full pass finds nothing left to send.
+	const bool live = i < n;
+	const uint32_t sg = live ? seg[i] : 0xFFFFFFFFu;
+	int32_t key = live ? f2total(expansion[i]) : INT32_MIN;
+	const uint32_t sg0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sg);
+	if (__ballot(live && sg != sg0) == 0ull && sg0 != 0xFFFFFFFFu) { // (lane 0 is live whenever any lane is: i ascends with the lane)
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
+		if ((threadIdx.x & 63u) == 0u && key > *(volatile const int32_t *)&best[sg0]) atomicMax(&best[sg0], key);
+		return;
+	}
+	if (!live || key <= *(volatile const int32_t *)&best[sg]) return;
 	atomicMax(&best[sg], key);
 }
 __device__ __forceinline__ uint32_t map_to_u32(float v) { // calculations.rs:455-457 (saturating cast, NaN -> 0)
@@ -905,7 +1042,9 @@ int32_t treee_display_values_dev(treee_ctx *ctx, const uint32_t *d_seg, uint64_t
 		// max_by(total_cmp).unwrap_or_default(): every queried segment has at least the querying point, so the start value
 		// (the smallest key of the total order) never survives where it is read
 		hipLaunchKernelGGL(k_init_i32, dim3(div_up(nseg, 256)), dim3(256), 0, ctx->stream, d_best, nseg, (int32_t)0x80000000);
-		hipLaunchKernelGGL(k_seg_max_expansion, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_expansion, d_seg, n, d_best);
+		constexpr uint32_t SAMPLE = 61;
+		if (n >= 65536u) hipLaunchKernelGGL(k_seg_max_expansion, dim3(div_up(div_up(n, SAMPLE), 256)), dim3(256), 0, ctx->stream, d_expansion, d_seg, n, SAMPLE, d_best);
+		hipLaunchKernelGGL(k_seg_max_expansion, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_expansion, d_seg, n, 1u, d_best);
 	}
 	hipLaunchKernelGGL(k_display_values, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_seg, d_cls, d_curve, d_expansion, d_height, n, d_best, d_cls_val,
 	                   d_curve_val, d_exp_val, d_height_val);
