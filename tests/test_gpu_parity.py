@@ -2054,6 +2054,34 @@ def test_full_size_15m_calculations_properties(T, oracle):
         assert np.array_equal(r.height[sel].cpu().numpy().view(np.uint32), h_o.view(np.uint32))
 
 
+def test_long_slices_whose_hull_is_cut_by_an_insertion(T, oracle):
+    """slices of 4 000 lattice points (a workgroup per slice, csrc/calculations.hip slice_hull_block).  On a lattice a new point
+    is often exactly collinear with a far edge of the hull, whose rounded normal then calls it outside: TWO runs of visible edges,
+    and the reference's splice (last start, last end: segmenting.rs:356-380) cuts a piece of the hull off.  The block kernel drops
+    points that lie well inside a coarse polygon of the hull before the reference's scan, which is only sound while hulls grow --
+    so it counts the runs of every insertion and does such a slice again without the filter.  A tree whose crown slices are such
+    lattices (the generator below shows two-run insertions at points ~200 ... 900 of a slice, behind and beyond the part one
+    wave inserts point by point), against the CPU restatement: every crown slice's area enters `expansion`, bit for bit."""
+    parts = []
+    rng = np.random.default_rng(5)
+    parts.append(np.stack([rng.normal(0, 0.05, 600), rng.uniform(0.0, 5.0, 600), rng.normal(0, 0.05, 600)], 1))  # trunk
+    for j, seed in enumerate((1, 3, 11, 2, 20, 16, 5, 14)):
+        g = np.random.default_rng(seed)
+        n = 4000
+        r = np.sqrt(np.arange(n) / n) * 40 + 3  # growing outwards: the hull keeps changing, with collinear lattice points
+        ang = g.random(n) * 2 * np.pi
+        xz = np.round(np.stack([r * np.cos(ang), r * np.sin(ang)], 1)) * (0.2 if j % 2 else 1.0)
+        parts.append(np.stack([xz[:, 0], np.full(n, 5.05 + 0.1 * j), xz[:, 1]], 1))
+    tree = np.concatenate(parts).astype(np.float32)
+    other = (np.random.default_rng(6).random((30_000, 3)) * np.array([30, 0.3, 30]) + np.array([100, 0, 0])).astype(np.float32)  # an ordinary ground beside it
+    pts = np.concatenate([tree, other])
+    seg = np.concatenate([np.zeros(len(tree), np.uint32), np.ones(len(other), np.uint32)])
+    got = _check_segments_against_oracle(T, oracle, pts, seg, 2, device=True)
+    assert (got["classification"][: len(tree)] == 2).sum() > 20_000 and np.isfinite(got["expansion"][: len(tree)]).all()
+    perm = np.random.default_rng(7).permutation(len(pts))  # (the order inside a slice is the cloud's: another order, another hull history)
+    _check_segments_against_oracle(T, oracle, pts[perm], seg[perm], 2)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_segments_calculate_fuzz_vs_oracle(T, oracle, seed):
     """random segment layouts, sizes and shapes -- lattice points (exact collinearity, duplicates, on-edge points: the

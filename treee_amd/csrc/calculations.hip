@@ -245,13 +245,10 @@ __device__ __forceinline__ bool edge_outside(P2 a, P2 nrm, P2 p) {
 
 // Slices of BIG_TASK points or more (the ground of a plot holds hundreds of thousands per slice) get a workgroup of 16
 // waves instead of one wave: 1024 points are tested per round, everything else is the same algorithm.
-#ifndef TREEE_BIG_PPT
-#define TREEE_BIG_PPT 1
-#endif
 #ifndef TREEE_BIG_ONE_BY_ONE
 #define TREEE_BIG_ONE_BY_ONE 512
 #endif
-constexpr uint32_t BIG_TASK = 2048, BIG_THREADS = 1024, BIG_LDS = 2048, BIG_PPT = TREEE_BIG_PPT, BIG_ONE_BY_ONE = TREEE_BIG_ONE_BY_ONE;
+constexpr uint32_t BIG_TASK = 2048, BIG_THREADS = 1024, BIG_LDS = 2048, BIG_ONE_BY_ONE = TREEE_BIG_ONE_BY_ONE;
 __global__ __launch_bounds__(256) void k_big_tasks(const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n, uint32_t *__restrict__ big_list,
                                                     uint32_t *__restrict__ big_count) {
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -295,7 +292,8 @@ __device__ __forceinline__ void insert_one_by_one(P2 *&H, P2 *&N, uint32_t &m, c
 		const uint64_t before = ((outside << 1) | (outside >> (m - 1u))) & all; // bit j = edge j - 1 (edge m - 1 for j = 0)
 		const uint64_t starts = outside & ~before, ends = ~outside & before;
 		if (starts == 0ull || ends == 0ull) continue; // inside (or outside every edge): Tree::insert returns without a change
-		splice(63u - (uint32_t)__builtin_clzll(starts), 63u - (uint32_t)__builtin_clzll(ends), px, py);
+		// (more than one run of outside edges: the reference's splice may then cut a piece of the hull off -- slice_hull_block counts on being told)
+		splice(63u - (uint32_t)__builtin_clzll(starts), 63u - (uint32_t)__builtin_clzll(ends), px, py, __popcll(starts) > 1);
 		fresh = false;
 	}
 }
@@ -329,7 +327,7 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 	};
 
 	// splice (segmenting.rs:374-380) of the point (px, py) between the edges s0 and e0, then the normals of the new hull
-	auto splice = [&](uint32_t s0, uint32_t e0, float px, float py) __attribute__((always_inline)) {
+	auto splice = [&](uint32_t s0, uint32_t e0, float px, float py, bool /*two_runs*/ = false) __attribute__((always_inline)) {
 		// splice (segmenting.rs:374-380), cooperative.  Lanes move in lockstep: every lane reads its element before any
 		// lane writes, and the chunks run in the direction that never overwrites an unread source.
 		// (new size first: a hull that outgrows its LDS copy moves to the task's HBM slot BEFORE anything is written --
@@ -483,241 +481,283 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 	}
 }
 
-// the same for one big slice per workgroup (see BIG_TASK)
-__device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS entries */, const float *__restrict__ xyz, const uint32_t *__restrict__ order,
-                                                 const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
-                                                 const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
-                                                 const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
+// The same for one big slice per workgroup (see BIG_TASK).  A ground slice holds 300 000 points and its hull ~40 edges; one
+// workgroup = one CU tests every point against every edge, and that alone was 1.2 ms of a 3 ms pass that had the other 255 CUs
+// idle at its end.  Nearly all of those points lie deep inside the hull that the slice's first points built, so:
+//   * FILTER.  COARSE vertices of the current hull, evenly spaced by index, are a convex polygon inside it.  A point inside
+//     that polygon by a margin (2^-14 of the coordinates' magnitude: ~600 x the rounding error of the reference's edge test)
+//     is inside every later hull by the same margin less a few roundings -- hulls only grow, see below -- so Tree::insert
+//     would return without a change: it is dropped after COARSE x 3 instructions.  The others (a few per cent) are
+//     compacted, in slice order, into an LDS buffer, and only they go through the reference's scan.
+//   * "HULLS ONLY GROW" holds while every insertion replaces ONE run of visible edges: the new hull then contains the old one
+//     up to slivers as thin as the test's rounding error.  A point that is (numerically) collinear with a far edge can show
+//     TWO runs, and the reference's splice (last start, last end: segmenting.rs:356-380) then cuts a piece of the hull off;
+//     points dropped earlier could matter again.  Every insertion therefore counts its runs, and a slice that sees such an
+//     insertion is done AGAIN from its first point with the filter off (bit for bit the reference either way).
+constexpr uint32_t COARSE = 12, BUF_CAP = 2048, BUF_GO = 1024;
+constexpr float COARSE_MARGIN = 6.103515625e-05f; // 2^-14
+__device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF_CAP entries */, const float *__restrict__ xyz,
+                                                 const uint32_t *__restrict__ order, const uint32_t *__restrict__ sorted_seg,
+                                                 const uint32_t *__restrict__ sorted_slice, const uint32_t *__restrict__ task_start, uint32_t n_tasks,
+                                                 uint32_t n, const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
                                                  const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count,
                                                  P2 *__restrict__ spill, float *__restrict__ areas) {
-	__shared__ uint32_t s_first, s_se[2];
+	__shared__ uint32_t s_first, s_se[3], s_m, s_done, s_wcnt[BIG_THREADS / 64u], s_two_runs;
 	__shared__ P2 s_p;
+	__shared__ float s_coarse[COARSE][3]; // outward unit normal of a coarse edge and the bound its points' n . p must stay under
 	if (blockIdx.x >= *big_count) return;
 	const uint32_t tid = threadIdx.x, t = big_list[blockIdx.x];
 	const uint32_t begin = task_start[t], end = t + 1u < n_tasks ? task_start[t + 1u] : n;
 	const uint32_t count = end - begin;
-	P2 *H = s_hull, *N = s_hull + BIG_LDS;
+	P2 *const s_buf = s_hull + 2u * BIG_LDS;
 	P2 *const big = spill + 2ull * begin + 4ull * t;
-	uint32_t cap = BIG_LDS, m = 0;
 	constexpr uint32_t NONE = 0xFFFFFFFFu;
-	auto normals = [&]() __attribute__((always_inline)) {
-		for (uint32_t c = 0; c < m; c += BIG_THREADS) {
-			const uint32_t j = c + tid;
-			if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
-		}
-		__syncthreads();
-	};
-	// move H[src .. src + len) to H[dst ..): every thread reads its element before any thread writes, chunks in the
-	// direction that never overwrites an unread source
-	auto move = [&](uint32_t src, uint32_t dst, uint32_t len) __attribute__((always_inline)) {
-		if (src == dst || len == 0u) return;
-		const uint32_t chunks = (len + BIG_THREADS - 1u) / BIG_THREADS;
-		for (uint32_t q = 0; q < chunks; ++q) {
-			const uint32_t c = dst < src ? q : chunks - 1u - q;
-			const uint32_t k = c * BIG_THREADS + tid;
-			P2 v = {0.0f, 0.0f};
-			if (k < len) v = H[src + k];
-			__syncthreads();
-			if (k < len) H[dst + k] = v;
-			__syncthreads();
-		}
-	};
-	// The first BIG_ONE_BY_ONE points: wave 0 alone, an edge per lane (insert_one_by_one) -- most of a long slice's changes
-	// happen there, and a change in the rounds below costs the whole workgroup a scan of the hull and seven barriers
-	__shared__ uint32_t s_m, s_done;
-	if (tid < 64u) {
-		uint32_t done = 0;
-		auto sync = [&]() __attribute__((always_inline)) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			__builtin_amdgcn_wave_barrier();
-		};
-		auto wave_normals = [&]() __attribute__((always_inline)) {
-			for (uint32_t c = 0; c < m; c += 64u) {
+	uint32_t m = 0;
+	P2 *H = s_hull, *N = s_hull + BIG_LDS; // generic pointers: LDS first, the task's HBM slot once the hull outgrows BIG_LDS
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		const bool filter_on = attempt == 0;
+		H = s_hull;
+		N = s_hull + BIG_LDS;
+		uint32_t cap = BIG_LDS;
+		m = 0;
+		if (tid == 0) s_two_runs = 0u;
+		auto normals = [&]() __attribute__((always_inline)) {
+			for (uint32_t c = 0; c < m; c += BIG_THREADS) {
 				const uint32_t j = c + tid;
 				if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
 			}
-			sync();
+			__syncthreads();
 		};
-		for (uint32_t base = 0; base < count && base < BIG_ONE_BY_ONE && m <= 64u; base += 64u) {
-			const uint32_t i = base + tid;
-			bool pending = i < count;
-			P2 p = {0.0f, 0.0f};
-			if (pending) {
-				const uint32_t o = order[begin + i];
-				p.x = xyz[3ull * o + 0];
-				p.y = xyz[3ull * o + 2];
-				if (cls) pending = cls[o] == want;
-			}
-			insert_one_by_one(
-			    H, N, m, p, pending, tid,
-			    [&](uint32_t s0, uint32_t e0, float px, float py) __attribute__((always_inline)) { // m <= 64 here: one chunk, LDS
-				    const bool wraps = e0 < s0;                                                     // H' = H[e0 ..= s0] + [point]
-				    const uint32_t len = wraps ? s0 - e0 + 1u : m - e0, dst = wraps ? 0u : s0 + 2u; // else H[0 ..= s0] + [point] + H[e0 .. m)
-				    P2 v = {0.0f, 0.0f};
-				    if (tid < len) v = H[e0 + tid];
-				    __builtin_amdgcn_wave_barrier();
-				    if (tid < len && dst != e0) H[dst + tid] = v;
-				    if (tid == 0) H[wraps ? len : s0 + 1u] = P2{px, py};
-				    m = wraps ? len + 1u : dst + len;
-				    sync();
-				    wave_normals();
-			    },
-			    [&](float px, float py) __attribute__((always_inline)) {
-				    if (tid == 0) {
-					    H[0] = P2{px, py};
-					    H[1] = P2{px + 0.1f, py};
-					    H[2] = P2{px, py + 0.1f};
-				    }
-				    m = 3;
-				    sync();
-				    wave_normals();
-			    });
-			const uint64_t left = __ballot(pending); // the hull outgrew 64 edges inside this batch: the rounds below take over there
-			done = left ? base + (uint32_t)__builtin_ctzll(left) : (base + 64u < count ? base + 64u : count);
-			if (left) break;
-		}
-		if (tid == 0) {
-			s_m = m;
-			s_done = done;
-		}
-	}
-	__syncthreads();
-	m = s_m;
-	// BIG_PPT points per thread and round: an edge is read once for all of them, and a round that changes nothing -- most
-	// rounds of a long slice -- retires BIG_PPT * 1024 points.  Point r of a round (slice order) = j * BIG_THREADS + tid.
-	for (uint32_t base = s_done; base < count; base += BIG_PPT * BIG_THREADS) {
-		bool pending[BIG_PPT];
-		P2 p[BIG_PPT];
-#pragma unroll
-		for (int j = 0; j < (int)BIG_PPT; ++j) {
-			const uint32_t i = base + (uint32_t)j * BIG_THREADS + tid;
-			pending[j] = i < count;
-			p[j] = P2{0.0f, 0.0f};
-			if (pending[j]) {
-				const uint32_t o = order[begin + i];
-				p[j].x = xyz[3ull * o + 0];
-				p[j].y = xyz[3ull * o + 2];
-				if (cls) pending[j] = cls[o] == want;
-			}
-		}
-		// rows [jlo, jhi) of the batch are tested in a round.  While the hull is still changing only the row of the last
-		// change is tested again (the rows before it are settled, testing the rows after it would be thrown away by the
-		// next change); once a row passes unchanged the window opens to the rest of the batch
-		uint32_t jlo = 0, jhi = 1;
-		for (;;) {
-			if (tid == 0) s_first = NONE;
-			__syncthreads();
-			bool has_s[BIG_PPT], has_e[BIG_PPT];
-			uint32_t st[BIG_PPT], en[BIG_PPT];
-#pragma unroll
-			for (int j = 0; j < (int)BIG_PPT; ++j) {
-				has_s[j] = has_e[j] = false;
-				st[j] = en[j] = 0u;
-			}
-			if (m == 0) { // Tree::new from the first point of the slice
-#pragma unroll
-				for (int j = 0; j < (int)BIG_PPT; ++j)
-					if (pending[j]) atomicMin(&s_first, (uint32_t)j * BIG_THREADS + tid);
-			} else {
-				bool live[BIG_PPT], any = false;
-#pragma unroll
-				for (int j = 0; j < (int)BIG_PPT; ++j) {
-					live[j] = pending[j] && (uint32_t)j >= jlo && (uint32_t)j < jhi;
-					any = any || live[j];
-				}
-				if (any) { // (a thread with nothing to test skips the scan; the barriers below are outside)
-					bool last[BIG_PPT];
-					{
-						const P2 hl = H[m - 1u], nl = N[m - 1u];
-#pragma unroll
-						for (int j = 0; j < (int)BIG_PPT; ++j) last[j] = edge_outside(hl, nl, p[j]);
-					}
-					auto edge = [&](uint32_t e, P2 hv, P2 nv) __attribute__((always_inline)) {
-#pragma unroll
-						for (int j = 0; j < (int)BIG_PPT; ++j) {
-							if ((uint32_t)j < jlo || (uint32_t)j >= jhi) continue; // uniform
-							const bool out = edge_outside(hv, nv, p[j]);
-							if (!last[j] && out) {
-								st[j] = e;
-								has_s[j] = true;
-							} else if (last[j] && !out) {
-								en[j] = e;
-								has_e[j] = true;
-							}
-							last[j] = out;
-						}
-					};
-					uint32_t e = 0;
-					for (; e + 4u <= m; e += 4u) { // four edges per trip: their eight reads are in flight together
-						P2 hv[4], nv[4];
-#pragma unroll
-						for (int u = 0; u < 4; ++u) {
-							hv[u] = H[e + u];
-							nv[u] = N[e + u];
-						}
-#pragma unroll
-						for (int u = 0; u < 4; ++u) edge(e + u, hv[u], nv[u]);
-					}
-					for (; e < m; ++e) edge(e, H[e], N[e]);
-#pragma unroll
-					for (int j = 0; j < (int)BIG_PPT; ++j)
-						if (live[j] && has_s[j] && has_e[j]) atomicMin(&s_first, (uint32_t)j * BIG_THREADS + tid);
-				}
-			}
-			__syncthreads();
-			const uint32_t f = s_first; // the first one in slice order (uniform)
-			if (f == NONE) {
-				if (m == 0 || jhi == BIG_PPT) break; // the whole batch is settled
-				jlo = jhi; // this window changed nothing: its rows are done, open the rest
-				jhi = BIG_PPT;
-				continue;
-			}
-			jlo = f / BIG_THREADS; // rows before the change are settled
-			jhi = jlo + 1u;
-			if (tid == f % BIG_THREADS) {
-#pragma unroll
-				for (int j = 0; j < (int)BIG_PPT; ++j)
-					if ((uint32_t)j == f / BIG_THREADS) {
-						s_se[0] = st[j];
-						s_se[1] = en[j];
-						s_p = p[j];
-					}
-			}
-			__syncthreads();
-			const uint32_t s0 = s_se[0], e0 = s_se[1];
-			const P2 np = s_p;
-			// (new size first, as in slice_hull_wave: the move to HBM happens before any write of either branch)
-			if (m != 0 && (e0 < s0 ? s0 - e0 + 2u : s0 + 2u + (m - e0)) > cap) {
-				for (uint32_t c = 0; c < m; c += BIG_THREADS)
-					if (c + tid < m) big[c + tid] = H[c + tid];
+		// move H[src .. src + len) to H[dst ..): every thread reads its element before any thread writes, chunks in the
+		// direction that never overwrites an unread source
+		auto move = [&](uint32_t src, uint32_t dst, uint32_t len) __attribute__((always_inline)) {
+			if (src == dst || len == 0u) return;
+			const uint32_t chunks = (len + BIG_THREADS - 1u) / BIG_THREADS;
+			for (uint32_t q = 0; q < chunks; ++q) {
+				const uint32_t c = dst < src ? q : chunks - 1u - q;
+				const uint32_t k = c * BIG_THREADS + tid;
+				P2 v = {0.0f, 0.0f};
+				if (k < len) v = H[src + k];
 				__syncthreads();
-				H = big;
-				N = big + (count + 2u);
-				cap = NONE;
+				if (k < len) H[dst + k] = v;
+				__syncthreads();
 			}
-			if (m == 0) {
-				if (tid == 0) {
-					H[0] = np;
-					H[1] = P2{np.x + 0.1f, np.y};
-					H[2] = P2{np.x, np.y + 0.1f};
+		};
+		// the coarse polygon of the current hull (any later hull contains it); m < COARSE or a degenerate edge (NaN bound)
+		// simply lets every point through
+		auto build_coarse = [&]() __attribute__((always_inline)) {
+			if (tid < COARSE) {
+				float nx = 0.0f, ny = 0.0f, bound = -INFINITY; // (nothing is under -inf: no point is dropped)
+				if (filter_on && m >= COARSE) {
+					const P2 a = H[(uint32_t)((uint64_t)tid * m / COARSE)], b = H[(uint32_t)((uint64_t)(tid + 1u) * m / COARSE) % m];
+					const P2 nrm = edge_normal(a, b);
+					nx = nrm.x;
+					ny = nrm.y;
+					bound = (nx * a.x + ny * a.y) - COARSE_MARGIN * (fabsf(a.x) + fabsf(a.y));
 				}
-				m = 3;
-			} else if (e0 < s0) { // H' = H[e0 ..= s0] + [point]
-				const uint32_t keep = s0 - e0 + 1u;
-				move(e0, 0u, keep);
-				if (tid == 0) H[keep] = np;
-				m = keep + 1u;
-			} else { // H' = H[0 ..= s0] + [point] + H[e0 .. m)
-				const uint32_t tail = m - e0, dst = s0 + 2u;
-				move(e0, dst, tail);
-				if (tid == 0) H[s0 + 1u] = np;
-				m = dst + tail;
+				s_coarse[tid][0] = nx;
+				s_coarse[tid][1] = ny;
+				s_coarse[tid][2] = bound;
 			}
-#pragma unroll
-			for (int j = 0; j < (int)BIG_PPT; ++j) pending[j] = pending[j] && (uint32_t)j * BIG_THREADS + tid > f;
 			__syncthreads();
-			normals();
+		};
+		// The first BIG_ONE_BY_ONE points: wave 0 alone, an edge per lane (insert_one_by_one) -- most of a long slice's changes
+		// happen there, and a change in the rounds below costs the whole workgroup a scan of the hull and seven barriers
+		__syncthreads(); // (s_two_runs; and, on the second attempt, everybody is done with the first)
+		if (tid < 64u) {
+			uint32_t done = 0;
+			auto sync = [&]() __attribute__((always_inline)) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_wave_barrier();
+			};
+			auto wave_normals = [&]() __attribute__((always_inline)) {
+				for (uint32_t c = 0; c < m; c += 64u) {
+					const uint32_t j = c + tid;
+					if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+				}
+				sync();
+			};
+			for (uint32_t base = 0; base < count && base < BIG_ONE_BY_ONE && m <= 64u; base += 64u) {
+				const uint32_t i = base + tid;
+				bool pending = i < count;
+				P2 p = {0.0f, 0.0f};
+				if (pending) {
+					const uint32_t o = order[begin + i];
+					p.x = xyz[3ull * o + 0];
+					p.y = xyz[3ull * o + 2];
+					if (cls) pending = cls[o] == want;
+				}
+				insert_one_by_one(
+				    H, N, m, p, pending, tid,
+				    [&](uint32_t s0, uint32_t e0, float px, float py, bool two_runs) __attribute__((always_inline)) { // m <= 64 here: one chunk, LDS
+					    const bool wraps = e0 < s0;                                                     // H' = H[e0 ..= s0] + [point]
+					    const uint32_t len = wraps ? s0 - e0 + 1u : m - e0, dst = wraps ? 0u : s0 + 2u; // else H[0 ..= s0] + [point] + H[e0 .. m)
+					    P2 v = {0.0f, 0.0f};
+					    if (tid < len) v = H[e0 + tid];
+					    __builtin_amdgcn_wave_barrier();
+					    if (tid < len && dst != e0) H[dst + tid] = v;
+					    if (tid == 0) H[wraps ? len : s0 + 1u] = P2{px, py};
+					    if (tid == 0 && two_runs) s_two_runs = 1u;
+					    m = wraps ? len + 1u : dst + len;
+					    sync();
+					    wave_normals();
+				    },
+				    [&](float px, float py) __attribute__((always_inline)) {
+					    if (tid == 0) {
+						    H[0] = P2{px, py};
+						    H[1] = P2{px + 0.1f, py};
+						    H[2] = P2{px, py + 0.1f};
+					    }
+					    m = 3;
+					    sync();
+					    wave_normals();
+				    });
+				const uint64_t left = __ballot(pending); // the hull outgrew 64 edges inside this batch: the rounds below take over there
+				done = left ? base + (uint32_t)__builtin_ctzll(left) : (base + 64u < count ? base + 64u : count);
+				if (left) break;
+			}
+			if (tid == 0) {
+				s_m = m;
+				s_done = done;
+			}
 		}
+		__syncthreads();
+		m = s_m;
+		uint32_t next = s_done; // the first point of the slice that has not been looked at
+		build_coarse();
+		while (next < count) {
+			// ---- fill: rounds of 1024 points through the filter, the survivors behind one another in the buffer ------------
+			uint32_t nbuf = 0;
+			while (next < count && nbuf < BUF_GO) {
+				const uint32_t i = next + tid;
+				bool keep = i < count;
+				P2 p = {0.0f, 0.0f};
+				if (keep) {
+					const uint32_t o = order[begin + i];
+					p.x = xyz[3ull * o + 0];
+					p.y = xyz[3ull * o + 2];
+					if (cls) keep = cls[o] == want;
+				}
+				if (keep) {
+					const float mag = COARSE_MARGIN * (fabsf(p.x) + fabsf(p.y));
+					bool inside = true;
+#pragma unroll
+					for (uint32_t j = 0; j < COARSE; ++j) inside = inside && (s_coarse[j][0] * p.x + s_coarse[j][1] * p.y) + mag <= s_coarse[j][2];
+					keep = !inside; // (NaN anywhere compares false: the point stays)
+				}
+				const uint64_t km = __ballot(keep);
+				if ((tid & 63u) == 0u) s_wcnt[tid >> 6] = (uint32_t)__popcll(km);
+				__syncthreads();
+				uint32_t before = nbuf, total = 0;
+#pragma unroll
+				for (uint32_t w = 0; w < BIG_THREADS / 64u; ++w) {
+					const uint32_t c = s_wcnt[w];
+					if (w < (tid >> 6)) before += c;
+					total += c;
+				}
+				if (keep) s_buf[before + (uint32_t)__popcll(km & ((1ull << (tid & 63u)) - 1ull))] = p;
+				nbuf += total;
+				next += BIG_THREADS;
+				__syncthreads(); // (s_wcnt is written again by the next round; s_buf is read below)
+			}
+			// ---- the reference's insertion over the buffered points, 1024 per batch ------------------------------------------
+			bool changed = false;
+			for (uint32_t sb = 0; sb < nbuf; sb += BIG_THREADS) {
+				bool pending = sb + tid < nbuf;
+				const P2 p = pending ? s_buf[sb + tid] : P2{0.0f, 0.0f};
+				for (;;) {
+					if (tid == 0) s_first = NONE;
+					__syncthreads();
+					bool has_s = false, has_e = false;
+					uint32_t st = 0, en = 0, runs = 0;
+					if (m == 0) { // Tree::new from the first point of the slice
+						if (pending) atomicMin(&s_first, tid);
+					} else if (pending) { // (a thread with nothing to test skips the scan; the barriers below are outside)
+						bool last = edge_outside(H[m - 1u], N[m - 1u], p);
+						auto edge = [&](uint32_t e, P2 hv, P2 nv) __attribute__((always_inline)) {
+							const bool out = edge_outside(hv, nv, p);
+							if (!last && out) {
+								st = e;
+								has_s = true;
+								++runs;
+							} else if (last && !out) {
+								en = e;
+								has_e = true;
+							}
+							last = out;
+						};
+						uint32_t e = 0;
+						for (; e + 4u <= m; e += 4u) { // four edges per trip: their eight reads are in flight together
+							P2 hv[4], nv[4];
+#pragma unroll
+							for (int u = 0; u < 4; ++u) {
+								hv[u] = H[e + u];
+								nv[u] = N[e + u];
+							}
+#pragma unroll
+							for (int u = 0; u < 4; ++u) edge(e + u, hv[u], nv[u]);
+						}
+						for (; e < m; ++e) edge(e, H[e], N[e]);
+						if (has_s && has_e) atomicMin(&s_first, tid);
+					}
+					__syncthreads();
+					const uint32_t f = s_first; // the first one in slice order (uniform)
+					if (f == NONE) break;       // the whole batch is settled
+					if (tid == f) {
+						s_se[0] = st;
+						s_se[1] = en;
+						s_se[2] = runs;
+						s_p = p;
+					}
+					__syncthreads();
+					const uint32_t s0 = s_se[0], e0 = s_se[1];
+					const P2 np = s_p;
+					if (tid == 0 && m != 0 && s_se[2] > 1u) s_two_runs = 1u;
+#ifdef TREEE_TEST_FORCE_SECOND_ATTEMPT // (validation build: every big slice is done twice, the second time without the filter)
+					if (tid == 0) s_two_runs = 1u;
+#endif
+					// (new size first, as in slice_hull_wave: the move to HBM happens before any write of either branch)
+					if (m != 0 && (e0 < s0 ? s0 - e0 + 2u : s0 + 2u + (m - e0)) > cap) {
+						for (uint32_t c = 0; c < m; c += BIG_THREADS)
+							if (c + tid < m) big[c + tid] = H[c + tid];
+						__syncthreads();
+						H = big;
+						N = big + (count + 2u);
+						cap = NONE;
+					}
+					if (m == 0) {
+						if (tid == 0) {
+							H[0] = np;
+							H[1] = P2{np.x + 0.1f, np.y};
+							H[2] = P2{np.x, np.y + 0.1f};
+						}
+						m = 3;
+					} else if (e0 < s0) { // H' = H[e0 ..= s0] + [point]
+						const uint32_t keep = s0 - e0 + 1u;
+						move(e0, 0u, keep);
+						if (tid == 0) H[keep] = np;
+						m = keep + 1u;
+					} else { // H' = H[0 ..= s0] + [point] + H[e0 .. m)
+						const uint32_t tail = m - e0, dst = s0 + 2u;
+						move(e0, dst, tail);
+						if (tid == 0) H[s0 + 1u] = np;
+						m = dst + tail;
+					}
+					pending = pending && tid > f;
+					changed = true;
+					__syncthreads();
+					normals();
+				}
+			}
+			if (changed && next < count) build_coarse(); // (uniform: every thread saw the same s_first values)
+		}
+		__syncthreads();
+		const uint32_t two_runs = s_two_runs;
+		__syncthreads(); // (thread 0 clears the word at the top of the next attempt)
+#ifdef TREEE_TEST_NO_SECOND_ATTEMPT // (validation build: shows that the tests notice a filtered slice whose hull was cut)
+		break;
+#endif
+		if (!filter_on || two_runs == 0u) break; // (uniform)
 	}
 	if (tid == 0 && m >= 3u) {
 		float area = 0.0f;
@@ -734,14 +774,15 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS entri
 // One launch for both kinds of slice: workgroups [0, big_max) take the big slices (those past *big_count leave at once;
 // being first in the grid, the long ones start first), the others take 16 ordinary slices each, one per wave.  As two
 // launches the ~20 workgroups of a plot's ground slices kept 236 CUs waiting for 3 ms.
-static_assert(2 * BIG_LDS == 16 * 2 * HULL_LDS, "both roles use the same 32 KiB of LDS");
-__global__ __launch_bounds__(BIG_THREADS) void k_slice_hulls(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
+static_assert(2 * BIG_LDS == 16 * 2 * HULL_LDS, "both roles use the same 32 KiB of LDS for their hulls");
+// (8 waves per SIMD = two workgroups per CU: without the attribute the block role's 106 SGPRs allow seven, i.e. ONE workgroup)
+__global__ __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_slice_hulls(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
                                                              const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
                                                              const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
                                                              const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count, uint32_t big_max,
                                                              P2 *__restrict__ spill, float *__restrict__ areas) {
-	__shared__ P2 s_mem[2 * BIG_LDS];
+	__shared__ P2 s_mem[2 * BIG_LDS + BUF_CAP];
 	if (blockIdx.x < big_max) {
 		slice_hull_block(s_mem, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want, slice_off, big_list, big_count, spill, areas);
 	} else {
