@@ -393,7 +393,23 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 		}
 		// (the first batch: an edge per lane, see insert_one_by_one)
 		if (base < EDGE_MODE_POINTS)
-			insert_one_by_one(H, N, m, p, pending, lane, splice, [&](float px, float py) __attribute__((always_inline)) {
+			insert_one_by_one(
+			    H, N, m, p, pending, lane,
+			    [&](uint32_t s0, uint32_t e0, float px, float py, bool) __attribute__((always_inline)) {
+				    if (cap != HULL_LDS) return splice(s0, e0, px, py); // (the hull once outgrew its LDS copy: the general code)
+				    // m <= 64 here and the new hull has at most 65 vertices: one chunk, every lane reads before any lane writes
+				    const bool wraps = e0 < s0;                                                     // H' = H[e0 ..= s0] + [point]
+				    const uint32_t len = wraps ? s0 - e0 + 1u : m - e0, dst = wraps ? 0u : s0 + 2u; // else H[0 ..= s0] + [point] + H[e0 .. m)
+				    P2 v = {0.0f, 0.0f};
+				    if (lane < len) v = H[e0 + lane];
+				    __builtin_amdgcn_wave_barrier();
+				    if (lane < len && dst != e0) H[dst + lane] = v;
+				    if (lane == 0) H[wraps ? len : s0 + 1u] = P2{px, py};
+				    m = wraps ? len + 1u : dst + len;
+				    sync();
+				    normals();
+			    },
+			    [&](float px, float py) __attribute__((always_inline)) {
 				if (lane == 0) {
 					H[0] = P2{px, py};
 					H[1] = P2{px + 0.1f, py};
