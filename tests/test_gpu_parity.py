@@ -2082,6 +2082,58 @@ def test_long_slices_whose_hull_is_cut_by_an_insertion(T, oracle):
     _check_segments_against_oracle(T, oracle, pts[perm], seg[perm], 2)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_long_slices_fuzz_vs_oracle(T, oracle, seed):
+    """the workgroup-per-slice path (>= 2 048 points in a 0.1 m slice: point-by-point start, coarse-polygon filter, compaction,
+    second attempt) on seeded slices of 2 500 ... 60 000 points and very different hulls -- discs and Gaussians (a few dozen
+    vertices, nearly every point filtered), rings (hundreds of vertices: past the 64 edges of the point-by-point start, some past
+    the 2 048 of the LDS copy), lattices and near-lines (collinear points, cut hulls), contour-like bands, far-off coordinates
+    (the filter's margin is relative), NaN and infinite coordinates in between -- stacked into crowns so that every slice's area
+    enters `expansion`; everything bit for bit against the CPU restatement."""
+    rng = np.random.default_rng(900 + seed)
+    S = 3
+    parts, ids = [], []
+    for sg in range(S):
+        c = rng.uniform(-200, 200, 3) * (1.0 if (seed + sg) % 3 else 40.0)  # (now and then ~8 km from the origin)
+        parts.append(c + np.stack([rng.normal(0, 0.05, 400), rng.uniform(0.0, 5.0, 400), rng.normal(0, 0.05, 400)], 1))  # trunk
+        ids.append(np.full(400, sg))
+        for j in range(int(rng.integers(2, 6))):
+            n = int(rng.choice([2_500, 5_000, 20_000, 60_000]))
+            kind = int(rng.integers(0, 7))
+            a = rng.random(n) * 2 * np.pi
+            if kind == 0:  # disc
+                r = np.sqrt(rng.random(n)) * rng.uniform(2, 30)
+                xz = np.stack([r * np.cos(a), r * np.sin(a)], 1)
+            elif kind == 1:  # Gaussian
+                xz = rng.standard_normal((n, 2)) * rng.uniform(0.5, 8)
+            elif kind == 2:  # ring: most points are hull vertices for a while
+                r = rng.uniform(5, 20) * (1 + rng.standard_normal(n) * 10.0 ** rng.uniform(-6, -2))
+                xz = np.stack([r * np.cos(a), r * np.sin(a)], 1)
+            elif kind == 3:  # lattice
+                xz = np.round(rng.standard_normal((n, 2)) * 12) * rng.choice([1.0, 0.25])
+            elif kind == 4:  # a contour band: an annulus sector with bumps
+                r = 25 + 3 * np.sin(5 * a) + rng.random(n) * 1.5
+                xz = np.stack([r * np.cos(a), r * np.sin(a)], 1)
+            elif kind == 5:  # nearly a line
+                u = rng.random(n) * 40
+                xz = np.stack([u, 0.3 * u + rng.standard_normal(n) * 1e-4], 1)
+            else:  # growing outwards: the hull changes until the end
+                r = np.sqrt(np.arange(n) / n) * 30 + rng.random(n)
+                xz = np.stack([r * np.cos(a), r * np.sin(a)], 1)
+            q = np.stack([c[0] + xz[:, 0], np.full(n, c[1] + 5.05 + 0.1 * j), c[2] + xz[:, 1]], 1)
+            parts.append(q)
+            ids.append(np.full(n, sg))
+    pts = np.concatenate(parts).astype(np.float32)
+    seg = np.concatenate(ids).astype(np.uint32)
+    if seed % 4 == 3:  # non-finite x / z in the middle of long slices (their y keeps them in the slice)
+        bad = rng.integers(1000, len(pts), 12)
+        pts[bad[:6], 0] = np.nan
+        pts[bad[6:9], 2] = np.inf
+        pts[bad[9:], 0] = -np.inf
+    perm = rng.permutation(len(pts))
+    _check_segments_against_oracle(T, oracle, pts[perm], seg[perm], S, device=bool(seed & 1))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_segments_calculate_fuzz_vs_oracle(T, oracle, seed):
     """random segment layouts, sizes and shapes -- lattice points (exact collinearity, duplicates, on-edge points: the
