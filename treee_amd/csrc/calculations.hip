@@ -257,6 +257,33 @@ __global__ __launch_bounds__(256) void k_big_tasks(const uint32_t *__restrict__ 
 	if (count >= BIG_TASK) big_list[atomicAdd(big_count, 1u)] = t; // (any order: the tasks are independent)
 }
 
+// The crown pass (calculations.rs:299-301: the slice hulls of the points classified Crown) needs a hull for ONE slice per segment.
+// A point is Crown iff neither y < ground_sep nor y < crown_sep (k_classify), i.e. y >= sep = max of the two, and the slice
+// index as_usize((y - min) / SLICE_WIDTH) never decreases with y; so every slice above sep's own holds Crown points only --
+// the same points in the same order as in the first pass: the same hull, the same area, bit for bit -- and every slice below
+// it holds none (area 0.0).  Only sep's slice is mixed (and slice 0, where a NaN height lands as Crown).
+struct CrownPass {
+	const float *seg_min, *seg_max, *seg_info; // null: not the crown pass
+	const uint32_t *n_slices;
+	const float *areas_all; // the first pass's areas
+};
+// true: the slice that starts at `begin` is settled (its area copied by `writer`, or left 0.0)
+__device__ __forceinline__ bool crown_slice_settled(const CrownPass &cp, uint32_t begin, const uint32_t *__restrict__ sorted_seg,
+                                                    const uint32_t *__restrict__ sorted_slice, const uint32_t *__restrict__ slice_off,
+                                                    float *__restrict__ areas, bool writer) {
+	if (!cp.areas_all) return false;
+	const uint32_t sg = sorted_seg[begin], sl = sorted_slice[begin];
+	const float crown_sep = cp.seg_max[sg * 3u + 1] - cp.seg_info[sg * 4u + 1]; // (k_classify's expressions)
+	const float ground_sep = crown_sep - cp.seg_info[sg * 4u + 0];
+	const float sep = fmaxf(ground_sep, crown_sep); // (drops a NaN operand; NaN if both are: every point is Crown, as_usize(NaN) = 0)
+	uint32_t s_sep = as_usize_u32((sep - cp.seg_min[sg * 3u + 1]) / SLICE_WIDTH);
+	const uint32_t ns = cp.n_slices[sg];
+	if (s_sep >= ns) s_sep = ns - 1u; // (k_slice_index's clamp)
+	if (sl == 0u || sl == s_sep) return false;
+	if (sl > s_sep && writer) areas[slice_off[sg] + sl] = cp.areas_all[slice_off[sg] + sl];
+	return true;
+}
+
 // The first points of a slice nearly all change the hull (a tree's slice holds ~20 points and ~10 of them do; a ground slice of
 // 300 000 makes most of its ~300 changes in its first few thousand), and in the batch loops below every change costs a scan of
 // the whole hull by every lane.  So the first points go the other way round while the hull has at most 64 edges: ONE EDGE PER
@@ -304,12 +331,13 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
                                                 const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
                                                 const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
                                                 const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
-                                                P2 *__restrict__ spill /* [2 * n + 4 * n_tasks] */, float *__restrict__ areas) {
+                                                P2 *__restrict__ spill /* [2 * n + 4 * n_tasks] */, float *__restrict__ areas, const CrownPass &cp) {
 	const uint32_t lane = threadIdx.x & 63u;
 	if (t >= n_tasks) return; // (whole waves leave: no block-wide barrier below)
 	const uint32_t begin = task_start[t], end = t + 1u < n_tasks ? task_start[t + 1u] : n;
 	const uint32_t count = end - begin;
 	if (count >= BIG_TASK) return; // a whole workgroup takes it (slice_hull_block)
+	if (crown_slice_settled(cp, begin, sorted_seg, sorted_slice, slice_off, areas, lane == 0u)) return;
 	P2 *H = lds, *N = lds + HULL_LDS; // vertices, then the outward normal of the edge that starts at each vertex; generic
 	                                  // pointers: LDS first, HBM after an overflow
 	P2 *const big = spill + 2ull * begin + 4ull * t; // room for count + 2 vertices and as many normals
@@ -517,7 +545,7 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
                                                  const uint32_t *__restrict__ sorted_slice, const uint32_t *__restrict__ task_start, uint32_t n_tasks,
                                                  uint32_t n, const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
                                                  const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count,
-                                                 P2 *__restrict__ spill, float *__restrict__ areas) {
+                                                 P2 *__restrict__ spill, float *__restrict__ areas, const CrownPass &cp) {
 	__shared__ uint32_t s_first, s_se[3], s_m, s_done, s_wcnt[BIG_THREADS / 64u], s_two_runs;
 	__shared__ P2 s_p;
 	__shared__ float s_coarse[COARSE][3]; // outward unit normal of a coarse edge and the bound its points' n . p must stay under
@@ -525,6 +553,7 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 	const uint32_t tid = threadIdx.x, t = big_list[blockIdx.x];
 	const uint32_t begin = task_start[t], end = t + 1u < n_tasks ? task_start[t + 1u] : n;
 	const uint32_t count = end - begin;
+	if (crown_slice_settled(cp, begin, sorted_seg, sorted_slice, slice_off, areas, tid == 0u)) return; // (uniform: before any barrier)
 	P2 *const s_buf = s_hull + 2u * BIG_LDS;
 	P2 *const big = spill + 2ull * begin + 4ull * t;
 	constexpr uint32_t NONE = 0xFFFFFFFFu;
@@ -797,14 +826,14 @@ __global__ __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
                                                              const uint32_t *__restrict__ task_start, uint32_t n_tasks, uint32_t n,
                                                              const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
                                                              const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count, uint32_t big_max,
-                                                             P2 *__restrict__ spill, float *__restrict__ areas) {
+                                                             P2 *__restrict__ spill, float *__restrict__ areas, const CrownPass cp) {
 	__shared__ P2 s_mem[2 * BIG_LDS + BUF_CAP];
 	if (blockIdx.x < big_max) {
-		slice_hull_block(s_mem, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want, slice_off, big_list, big_count, spill, areas);
+		slice_hull_block(s_mem, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want, slice_off, big_list, big_count, spill, areas, cp);
 	} else {
 		const uint32_t w = threadIdx.x >> 6;
 		slice_hull_wave(s_mem + w * 2u * HULL_LDS, (blockIdx.x - big_max) * 16u + w, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want,
-		                slice_off, spill, areas);
+		                slice_off, spill, areas, cp);
 	}
 }
 
@@ -1064,19 +1093,22 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st)); // a slice without points has area 0.0
 	if (n_tasks)
 		hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 16)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
-		                   nullptr, 0u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_areas);
+		                   nullptr, 0u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_areas, CrownPass{nullptr, nullptr, nullptr, nullptr, nullptr});
 	hipLaunchKernelGGL(k_seg_info, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_max, nseg, d_seg_info);
 	if (n && d_cls) hipLaunchKernelGGL(k_classify, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, n, d_seg_max, d_seg_info, d_cls);
 	TREEE_LAUNCH_CHECK();
 	// 4. SegmentInformation::update: crown-only slice areas -> expansion; height
 	if (n && (d_expansion || d_height)) {
+		float *d_crown = d_areas; // (unused when there is no expansion to write)
 		if (d_expansion) {
-			TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st));
+			// the crown points' slice areas: one slice per segment needs its hull built again, the others are copies or 0.0 (CrownPass)
+			TREEE_TRY(ctx->alloc_t((size_t)total_slices + 1, &d_crown));
+			TREEE_HIP(hipMemsetAsync(d_crown, 0, ((size_t)total_slices + 1) * 4, st));
 			hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 16)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
-			                   d_cls, 2u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_areas);
-			hipLaunchKernelGGL(k_seg_expansion, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_info, nseg);
+			                   d_cls, 2u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_crown, CrownPass{d_seg_min, d_seg_max, d_seg_info, d_nsl, d_areas});
+			hipLaunchKernelGGL(k_seg_expansion, dim3(gs), dim3(256), 0, st, d_crown, d_sloff, d_nsl, d_seg_min, d_seg_info, nseg);
 		}
-		hipLaunchKernelGGL(k_point_properties, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, d_slice, n, d_areas, d_sloff, d_seg_min, d_seg_max, d_expansion, d_height);
+		hipLaunchKernelGGL(k_point_properties, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, d_slice, n, d_crown, d_sloff, d_seg_min, d_seg_max, d_expansion, d_height);
 		TREEE_LAUNCH_CHECK();
 	}
 	return TREEE_OK;
