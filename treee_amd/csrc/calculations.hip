@@ -207,6 +207,17 @@ __global__ __launch_bounds__(256) void k_gather(const uint32_t *__restrict__ src
 	if (i < n) dst[i] = src[idx[i]];
 }
 // task = run of equal (segment, slice) in the final order; flag its first element
+__global__ __launch_bounds__(256) void k_join_keys(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ slice, uint32_t n, uint32_t *__restrict__ key) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i < n) key[i] = (seg[i] << SLICE_BITS) | slice[i]; // (slice < 2^SLICE_BITS - 1: k_seg_finish_aabb caps the count)
+}
+__global__ __launch_bounds__(256) void k_split_keys(const uint32_t *__restrict__ key, uint32_t n, uint32_t *__restrict__ seg, uint32_t *__restrict__ slice) {
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t k = key[i];
+	seg[i] = k >> SLICE_BITS;
+	slice[i] = k & ((1u << SLICE_BITS) - 1u);
+}
 __global__ __launch_bounds__(256) void k_task_flags(const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice, uint32_t n,
                                                      uint32_t *__restrict__ flag) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -1059,11 +1070,20 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	if (n) {
 		hipLaunchKernelGGL(k_slice_index, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, n, d_seg_min, d_nsl, d_slice);
 		TREEE_LAUNCH_CHECK();
-		TREEE_TRY(sort_pairs_dev(ctx, d_slice, nullptr, n, (int)SLICE_BITS, d_slice_s, d_permA));
-		hipLaunchKernelGGL(k_gather, dim3(gn), dim3(256), 0, st, d_seg, d_permA, n, d_segA);
-		TREEE_LAUNCH_CHECK();
-		TREEE_TRY(sort_pairs_dev(ctx, d_segA, d_permA, n, sbits, d_segF, d_order));
-		hipLaunchKernelGGL(k_gather, dim3(gn), dim3(256), 0, st, d_slice, d_order, n, d_sliceF);
+		if (sbits + (int)SLICE_BITS <= 32) {
+			// one stable sort by (segment << SLICE_BITS | slice) is the same permutation as a stable sort by slice followed by a
+			// stable sort by segment -- and leaves both keys in final order without the two gathers (0.5 ms of a 15 M-point cloud)
+			hipLaunchKernelGGL(k_join_keys, dim3(gn), dim3(256), 0, st, d_seg, d_slice, n, d_segA);
+			TREEE_LAUNCH_CHECK();
+			TREEE_TRY(sort_pairs_dev(ctx, d_segA, nullptr, n, sbits + (int)SLICE_BITS, d_slice_s, d_order));
+			hipLaunchKernelGGL(k_split_keys, dim3(gn), dim3(256), 0, st, d_slice_s, n, d_segF, d_sliceF);
+		} else { // more than 65 536 segments: two sorts
+			TREEE_TRY(sort_pairs_dev(ctx, d_slice, nullptr, n, (int)SLICE_BITS, d_slice_s, d_permA));
+			hipLaunchKernelGGL(k_gather, dim3(gn), dim3(256), 0, st, d_seg, d_permA, n, d_segA);
+			TREEE_LAUNCH_CHECK();
+			TREEE_TRY(sort_pairs_dev(ctx, d_segA, d_permA, n, sbits, d_segF, d_order));
+			hipLaunchKernelGGL(k_gather, dim3(gn), dim3(256), 0, st, d_slice, d_order, n, d_sliceF);
+		}
 		hipLaunchKernelGGL(k_task_flags, dim3(gn), dim3(256), 0, st, d_segF, d_sliceF, n, d_flag);
 		TREEE_LAUNCH_CHECK();
 		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_flag, d_task_of, n, d_total + 1));
