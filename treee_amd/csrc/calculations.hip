@@ -336,6 +336,111 @@ __device__ __forceinline__ void insert_one_by_one(P2 *&H, P2 *&N, uint32_t &m, c
 	}
 }
 
+// FOUR SHORT SLICES PER WAVE, one per row of 16 lanes.  A tree's slice holds ~20 points of which ~12 change the hull, and a hull of
+// such a slice has at most 16 vertices 97 % of the time: a whole wave per slice (insert_one_by_one) leaves three quarters of its
+// lanes idle through the ~100 instructions a change costs (the reference's normalisation is a square root and two divisions).
+// Here a row holds its slice's hull in REGISTERS (lane j = vertex j and the normal of the edge that starts there), its points wait
+// in LDS, and the four rows step through their own points in lockstep: one edge test per lane, the reference's scan
+// (segmenting.rs:356-370) as bit arithmetic on the row's 16 bits of the ballot, the splice (:374-380) as one lane permutation.
+// Same insertions in the same order with the same arithmetic: the same hull, vertex for vertex.  Returns a ballot with bit 16 r
+// set for every row whose slice is left to the whole wave (slice_hull_wave): more than 64 points, or a hull that outgrew 16.
+__device__ __forceinline__ uint64_t slice_hulls_rows(P2 *pts /* this wave's 4 x 64 entries */, uint32_t t0, const float *__restrict__ xyz,
+                                                     const uint32_t *__restrict__ order, const uint32_t *__restrict__ sorted_seg,
+                                                     const uint32_t *__restrict__ sorted_slice, const uint32_t *__restrict__ task_start,
+                                                     uint32_t n_tasks, uint32_t n, const uint32_t *__restrict__ cls, uint32_t want,
+                                                     const uint32_t *__restrict__ slice_off, float *__restrict__ areas, const CrownPass &cp) {
+	const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, j = lane & 15u, row_base = lane & 48u;
+	const uint32_t t = t0 + row;
+	uint32_t begin = 0, count = 0;
+	if (t < n_tasks) {
+		begin = task_start[t];
+		count = (t + 1u < n_tasks ? task_start[t + 1u] : n) - begin;
+	}
+	bool redo = t < n_tasks && count > 64u && count < BIG_TASK; // (a big slice has its own workgroup)
+	bool packed = t < n_tasks && count <= 64u;
+	if (packed && crown_slice_settled(cp, begin, sorted_seg, sorted_slice, slice_off, areas, j == 0u)) packed = false;
+	// the row's points, in slice order, those of another class left out
+	uint32_t cnt = 0;
+#pragma unroll
+	for (uint32_t q = 0; q < 4u; ++q) {
+		const uint32_t i = q * 16u + j;
+		bool keep = packed && i < count;
+		P2 p = {0.0f, 0.0f};
+		if (keep) {
+			const uint32_t o = order[begin + i];
+			p.x = xyz[3ull * o + 0];
+			p.y = xyz[3ull * o + 2];
+			if (cls) keep = cls[o] == want;
+		}
+		const uint32_t km = (uint32_t)(__ballot(keep) >> row_base) & 0xFFFFu;
+		if (keep) pts[row * 64u + cnt + (uint32_t)__popc(km & ((1u << j) - 1u))] = p;
+		cnt += (uint32_t)__popc(km);
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	uint32_t k = 0, m = 0; // next point, hull size (0 = no Tree yet): the same in all lanes of a row
+	P2 hv = {0.0f, 0.0f}, nv = {0.0f, 0.0f};
+	for (;;) {
+		const bool live = k < cnt;
+		if (__ballot(live) == 0ull) break;
+		const P2 p = pts[row * 64u + (live ? k : 0u)];
+		bool changed = false;
+		// Tree::insert, scan part: this lane's edge; then the row's 16 bits
+		const bool test = live && m != 0u;
+		const uint32_t O = (uint32_t)(__ballot(test && j < m && edge_outside(hv, nv, p)) >> row_base) & 0xFFFFu;
+		const uint32_t all = (1u << m) - 1u;
+		const uint32_t before = ((O << 1) | (O >> (m ? m - 1u : 0u))) & all; // bit e = edge e - 1 (edge m - 1 for e = 0)
+		const uint32_t starts = O & ~before, ends = ~O & before;
+		const bool mod = test && starts != 0u && ends != 0u;
+		const uint32_t s0 = 31u - (uint32_t)__clz((int)(starts | 1u)), e0 = 31u - (uint32_t)__clz((int)(ends | 1u));
+		const bool wraps = e0 < s0;                                                     // H' = H[e0 ..= s0] + [point]
+		const uint32_t len = wraps ? s0 - e0 + 1u : m - e0, dst = wraps ? 0u : s0 + 2u; // else H[0 ..= s0] + [point] + H[e0 .. m)
+		const uint32_t new_m = wraps ? len + 1u : dst + len;
+		uint32_t src = j;
+		bool is_point = false;
+		if (wraps) {
+			if (j < len) src = e0 + j;
+			is_point = j == len;
+		} else {
+			is_point = j == s0 + 1u;
+			if (j >= dst) src = e0 + (j - dst);
+		}
+		// (all 64 lanes take part in the permutation: no branch around it)
+		const float sx = __shfl(hv.x, (int)(row_base + (src & 15u)), 64), sy = __shfl(hv.y, (int)(row_base + (src & 15u)), 64);
+		if (mod) {
+			if (new_m > 16u) { // the hull outgrows the row: the whole wave does this slice again
+				redo = true;
+				cnt = 0;
+			} else {
+				hv = is_point ? p : P2{sx, sy};
+				m = new_m;
+				changed = true;
+			}
+		} else if (live && m == 0u) { // Tree::new (segmenting.rs:258-269)
+			hv = j == 0u ? p : (j == 1u ? P2{p.x + 0.1f, p.y} : P2{p.x, p.y + 0.1f});
+			m = 3;
+			changed = true;
+		}
+		if (__ballot(changed) != 0ull) { // the normals of the new hull (every edge again, as the reference's every test does)
+			const uint32_t nxt = j + 1u < m ? j + 1u : 0u;
+			const float qx = __shfl(hv.x, (int)(row_base + nxt), 64), qy = __shfl(hv.y, (int)(row_base + nxt), 64);
+			const P2 nn = edge_normal(hv, P2{qx, qy});
+			if (changed) nv = nn;
+		}
+		k += live ? 1u : 0u;
+	}
+	// Tree::statistics().area: the triangle fan around vertex 0, summed in order (segmenting.rs:526-545)
+	const float ax = __shfl(hv.x, (int)row_base, 64), ay = __shfl(hv.y, (int)row_base, 64);
+	float area = 0.0f;
+	for (uint32_t i = 1; i + 1u < 16u; ++i) {
+		const float bx = __shfl(hv.x, (int)(row_base + i), 64) - ax, by = __shfl(hv.y, (int)(row_base + i), 64) - ay;
+		const float cx = __shfl(hv.x, (int)(row_base + i + 1u), 64) - ax, cy = __shfl(hv.y, (int)(row_base + i + 1u), 64) - ay;
+		if (i + 1u < m) area += bx * cy - by * cx;
+	}
+	if (packed && !redo && j == 0u && m >= 3u) areas[slice_off[sorted_seg[begin]] + sorted_slice[begin]] = area / 2.0f;
+	return __ballot(redo && j == 0u);
+}
+
 // one wave per task.  `cls` (optional): only points with cls[orig] == want take part (calculations.rs:299-301).
 __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_LDS entries */, uint32_t t, const float *__restrict__ xyz,
                                                 const uint32_t *__restrict__ order /* final order -> original index */,
@@ -549,7 +654,7 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 //     TWO runs, and the reference's splice (last start, last end: segmenting.rs:356-380) then cuts a piece of the hull off;
 //     points dropped earlier could matter again.  Every insertion therefore counts its runs, and a slice that sees such an
 //     insertion is done AGAIN from its first point with the filter off (bit for bit the reference either way).
-constexpr uint32_t COARSE = 12, BUF_CAP = 2048, BUF_GO = 1024;
+constexpr uint32_t COARSE = 12, BUF_CAP = 2048, BUF_GO = 1024, FILL_PPT = 2;
 constexpr float COARSE_MARGIN = 6.103515625e-05f; // 2^-14
 __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF_CAP entries */, const float *__restrict__ xyz,
                                                  const uint32_t *__restrict__ order, const uint32_t *__restrict__ sorted_seg,
@@ -557,7 +662,7 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
                                                  uint32_t n, const uint32_t *__restrict__ cls, uint32_t want, const uint32_t *__restrict__ slice_off,
                                                  const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ big_count,
                                                  P2 *__restrict__ spill, float *__restrict__ areas, const CrownPass &cp) {
-	__shared__ uint32_t s_first, s_se[3], s_m, s_done, s_wcnt[BIG_THREADS / 64u], s_two_runs;
+	__shared__ uint32_t s_first, s_se[3], s_m, s_done, s_wcnt[FILL_PPT][BIG_THREADS / 64u], s_two_runs;
 	__shared__ P2 s_p;
 	__shared__ float s_coarse[COARSE][3]; // outward unit normal of a coarse edge and the bound its points' n . p must stay under
 	if (blockIdx.x >= *big_count) return;
@@ -620,19 +725,46 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 		// The first BIG_ONE_BY_ONE points: wave 0 alone, an edge per lane (insert_one_by_one) -- most of a long slice's changes
 		// happen there, and a change in the rounds below costs the whole workgroup a scan of the hull and seven barriers
 		__syncthreads(); // (s_two_runs; and, on the second attempt, everybody is done with the first)
+		// wave 0's tools for inserting points one by one (insert_one_by_one): hull in LDS, at most 64 edges before an insertion
+		bool spliced = false;
+		auto wave_sync = [&]() __attribute__((always_inline)) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+		};
+		auto wave_normals = [&]() __attribute__((always_inline)) {
+			for (uint32_t c = 0; c < m; c += 64u) {
+				const uint32_t j = c + tid;
+				if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+			}
+			wave_sync();
+		};
+		auto wave_splice = [&](uint32_t s0, uint32_t e0, float px, float py, bool two_runs) __attribute__((always_inline)) { // one chunk
+			const bool wraps = e0 < s0;                                                     // H' = H[e0 ..= s0] + [point]
+			const uint32_t len = wraps ? s0 - e0 + 1u : m - e0, dst = wraps ? 0u : s0 + 2u; // else H[0 ..= s0] + [point] + H[e0 .. m)
+			P2 v = {0.0f, 0.0f};
+			if (tid < len) v = H[e0 + tid];
+			__builtin_amdgcn_wave_barrier();
+			if (tid < len && dst != e0) H[dst + tid] = v;
+			if (tid == 0) H[wraps ? len : s0 + 1u] = P2{px, py};
+			if (tid == 0 && two_runs) s_two_runs = 1u;
+			m = wraps ? len + 1u : dst + len;
+			spliced = true;
+			wave_sync();
+			wave_normals();
+		};
+		auto wave_new_tree = [&](float px, float py) __attribute__((always_inline)) {
+			if (tid == 0) {
+				H[0] = P2{px, py};
+				H[1] = P2{px + 0.1f, py};
+				H[2] = P2{px, py + 0.1f};
+			}
+			m = 3;
+			spliced = true;
+			wave_sync();
+			wave_normals();
+		};
 		if (tid < 64u) {
 			uint32_t done = 0;
-			auto sync = [&]() __attribute__((always_inline)) {
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				__builtin_amdgcn_wave_barrier();
-			};
-			auto wave_normals = [&]() __attribute__((always_inline)) {
-				for (uint32_t c = 0; c < m; c += 64u) {
-					const uint32_t j = c + tid;
-					if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
-				}
-				sync();
-			};
 			for (uint32_t base = 0; base < count && base < BIG_ONE_BY_ONE && m <= 64u; base += 64u) {
 				const uint32_t i = base + tid;
 				bool pending = i < count;
@@ -643,31 +775,7 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 					p.y = xyz[3ull * o + 2];
 					if (cls) pending = cls[o] == want;
 				}
-				insert_one_by_one(
-				    H, N, m, p, pending, tid,
-				    [&](uint32_t s0, uint32_t e0, float px, float py, bool two_runs) __attribute__((always_inline)) { // m <= 64 here: one chunk, LDS
-					    const bool wraps = e0 < s0;                                                     // H' = H[e0 ..= s0] + [point]
-					    const uint32_t len = wraps ? s0 - e0 + 1u : m - e0, dst = wraps ? 0u : s0 + 2u; // else H[0 ..= s0] + [point] + H[e0 .. m)
-					    P2 v = {0.0f, 0.0f};
-					    if (tid < len) v = H[e0 + tid];
-					    __builtin_amdgcn_wave_barrier();
-					    if (tid < len && dst != e0) H[dst + tid] = v;
-					    if (tid == 0) H[wraps ? len : s0 + 1u] = P2{px, py};
-					    if (tid == 0 && two_runs) s_two_runs = 1u;
-					    m = wraps ? len + 1u : dst + len;
-					    sync();
-					    wave_normals();
-				    },
-				    [&](float px, float py) __attribute__((always_inline)) {
-					    if (tid == 0) {
-						    H[0] = P2{px, py};
-						    H[1] = P2{px + 0.1f, py};
-						    H[2] = P2{px, py + 0.1f};
-					    }
-					    m = 3;
-					    sync();
-					    wave_normals();
-				    });
+				insert_one_by_one(H, N, m, p, pending, tid, wave_splice, wave_new_tree);
 				const uint64_t left = __ballot(pending); // the hull outgrew 64 edges inside this batch: the rounds below take over there
 				done = left ? base + (uint32_t)__builtin_ctzll(left) : (base + 64u < count ? base + 64u : count);
 				if (left) break;
@@ -680,47 +788,125 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 		__syncthreads();
 		m = s_m;
 		uint32_t next = s_done; // the first point of the slice that has not been looked at
+		bool wide = false;      // the next fill round takes FILL_PPT points per thread
 		build_coarse();
 		while (next < count) {
-			// ---- fill: rounds of 1024 points through the filter, the survivors behind one another in the buffer ------------
+			// ---- fill: rounds of FILL_PPT x 1024 points through the filter, the survivors behind one another in the buffer.  A
+			// round is two dependent gathers (order -> x, z) and was ~4 us of latency per 1 024 points: four points per thread have
+			// their loads in flight together.  A round whose survivors would not fit is not committed and done again point by
+			// point per thread (the filter is off, the hull still small, or the slice just left the coarse polygon)
 			uint32_t nbuf = 0;
 			while (next < count && nbuf < BUF_GO) {
-				const uint32_t i = next + tid;
-				bool keep = i < count;
-				P2 p = {0.0f, 0.0f};
-				if (keep) {
-					const uint32_t o = order[begin + i];
-					p.x = xyz[3ull * o + 0];
-					p.y = xyz[3ull * o + 2];
-					if (cls) keep = cls[o] == want;
-				}
-				if (keep) {
-					const float mag = COARSE_MARGIN * (fabsf(p.x) + fabsf(p.y));
-					bool inside = true;
+				const uint32_t ppt = wide ? FILL_PPT : 1u;
+				bool keep[FILL_PPT];
+				P2 p[FILL_PPT];
 #pragma unroll
-					for (uint32_t j = 0; j < COARSE; ++j) inside = inside && (s_coarse[j][0] * p.x + s_coarse[j][1] * p.y) + mag <= s_coarse[j][2];
-					keep = !inside; // (NaN anywhere compares false: the point stays)
+				for (uint32_t q = 0; q < FILL_PPT; ++q) {
+					const uint32_t i = next + q * BIG_THREADS + tid;
+					keep[q] = q < ppt && i < count;
+					p[q] = P2{0.0f, 0.0f};
+					if (keep[q]) {
+						const uint32_t o = order[begin + i];
+						p[q].x = xyz[3ull * o + 0];
+						p[q].y = xyz[3ull * o + 2];
+						if (cls) keep[q] = cls[o] == want;
+					}
 				}
-				const uint64_t km = __ballot(keep);
-				if ((tid & 63u) == 0u) s_wcnt[tid >> 6] = (uint32_t)__popcll(km);
+				uint64_t km[FILL_PPT];
+#pragma unroll
+				for (uint32_t q = 0; q < FILL_PPT; ++q) {
+					if (keep[q]) {
+						const float mag = COARSE_MARGIN * (fabsf(p[q].x) + fabsf(p[q].y));
+						bool inside = true;
+#pragma unroll
+						for (uint32_t j = 0; j < COARSE; ++j) inside = inside && (s_coarse[j][0] * p[q].x + s_coarse[j][1] * p[q].y) + mag <= s_coarse[j][2];
+						keep[q] = !inside; // (NaN anywhere compares false: the point stays)
+					}
+					km[q] = __ballot(keep[q]);
+					if ((tid & 63u) == 0u) s_wcnt[q][tid >> 6] = (uint32_t)__popcll(km[q]);
+				}
 				__syncthreads();
-				uint32_t before = nbuf, total = 0;
+				uint32_t before[FILL_PPT], total = 0; // slice order inside a round: row q (1 024 points) after row q - 1, waves in order
 #pragma unroll
-				for (uint32_t w = 0; w < BIG_THREADS / 64u; ++w) {
-					const uint32_t c = s_wcnt[w];
-					if (w < (tid >> 6)) before += c;
-					total += c;
+				for (uint32_t q = 0; q < FILL_PPT; ++q) {
+					before[q] = nbuf + total;
+#pragma unroll
+					for (uint32_t w = 0; w < BIG_THREADS / 64u; ++w) {
+						const uint32_t c = s_wcnt[q][w];
+						if (w < (tid >> 6)) before[q] += c;
+						total += c;
+					}
 				}
-				if (keep) s_buf[before + (uint32_t)__popcll(km & ((1ull << (tid & 63u)) - 1ull))] = p;
-				nbuf += total;
-				next += BIG_THREADS;
+				const bool fits = nbuf + total <= BUF_CAP; // (uniform; always true with one point per thread: nbuf < BUF_GO)
+				if (fits) {
+#pragma unroll
+					for (uint32_t q = 0; q < FILL_PPT; ++q)
+						if (keep[q]) s_buf[before[q] + (uint32_t)__popcll(km[q] & ((1ull << (tid & 63u)) - 1ull))] = p[q];
+					nbuf += total;
+					next += ppt * BIG_THREADS;
+					wide = total * 4u <= BIG_THREADS * ppt; // few survivors: the next round can be a wide one
+				} else {
+					wide = false;
+				}
 				__syncthreads(); // (s_wcnt is written again by the next round; s_buf is read below)
 			}
 			// ---- the reference's insertion over the buffered points, 1024 per batch ------------------------------------------
 			bool changed = false;
 			for (uint32_t sb = 0; sb < nbuf; sb += BIG_THREADS) {
 				bool pending = sb + tid < nbuf;
-				const P2 p = pending ? s_buf[sb + tid] : P2{0.0f, 0.0f};
+				P2 p = pending ? s_buf[sb + tid] : P2{0.0f, 0.0f};
+				// A change of the hull costs the rounds below a scan by every thread and seven barriers (~6 us), and a ground slice
+				// makes ~150 of them after its first points.  While the hull has at most 64 edges the batch is therefore tested ONCE,
+				// in parallel, against the real hull with the filter's margin -- a point inside by the margin is inside every later
+				// hull (see above) and is dropped --, and the few that remain are inserted one by one by wave 0, an edge per lane.
+				// (Not on the second attempt: there a hull has been cut, and nothing may be dropped.)
+				if (filter_on && m != 0u && m <= 64u && cap == BIG_LDS) {
+					bool rest = pending;
+					if (pending) {
+						const float mag = fabsf(p.x) + fabsf(p.y);
+						bool inside = true;
+						for (uint32_t e = 0; e < m; ++e) {
+							const P2 hv = H[e], nv = N[e];
+							const float fx = p.x - hv.x, fy = p.y - hv.y;
+							inside = inside && nv.x * fx + nv.y * fy <= -COARSE_MARGIN * (mag + fabsf(hv.x) + fabsf(hv.y));
+						}
+						rest = !inside; // (NaN anywhere compares false: the point stays)
+					}
+					const uint64_t km = __ballot(rest);
+					if ((tid & 63u) == 0u) s_wcnt[0][tid >> 6] = (uint32_t)__popcll(km);
+					__syncthreads(); // (every thread holds its s_buf[sb + tid] by now: the compaction below is in place)
+					uint32_t before = 0, total = 0;
+#pragma unroll
+					for (uint32_t w = 0; w < BIG_THREADS / 64u; ++w) {
+						const uint32_t c = s_wcnt[0][w];
+						if (w < (tid >> 6)) before += c;
+						total += c;
+					}
+					if (rest) s_buf[sb + before + (uint32_t)__popcll(km & ((1ull << (tid & 63u)) - 1ull))] = p;
+					__syncthreads();
+					if (tid < 64u) {
+						uint32_t done = 0;
+						spliced = false;
+						for (uint32_t base = 0; base < total && m <= 64u; base += 64u) {
+							bool pend = base + tid < total;
+							const P2 q = pend ? s_buf[sb + base + tid] : P2{0.0f, 0.0f};
+							insert_one_by_one(H, N, m, q, pend, tid, wave_splice, wave_new_tree);
+							const uint64_t left = __ballot(pend); // the hull outgrew 64 edges: the rounds below take the others
+							done = left ? base + (uint32_t)__builtin_ctzll(left) : (base + 64u < total ? base + 64u : total);
+							if (left) break;
+						}
+						if (tid == 0) {
+							s_m = m;
+							s_done = done;
+							s_se[0] = spliced ? 1u : 0u;
+						}
+					}
+					__syncthreads();
+					m = s_m;
+					changed = changed || s_se[0] != 0u;
+					pending = tid >= s_done && tid < total; // (nobody, unless the hull outgrew 64 edges on the way)
+					p = pending ? s_buf[sb + tid] : P2{0.0f, 0.0f};
+				}
 				for (;;) {
 					if (tid == 0) s_first = NONE;
 					__syncthreads();
@@ -830,7 +1016,8 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 // One launch for both kinds of slice: workgroups [0, big_max) take the big slices (those past *big_count leave at once;
 // being first in the grid, the long ones start first), the others take 16 ordinary slices each, one per wave.  As two
 // launches the ~20 workgroups of a plot's ground slices kept 236 CUs waiting for 3 ms.
-static_assert(2 * BIG_LDS == 16 * 2 * HULL_LDS, "both roles use the same 32 KiB of LDS for their hulls");
+constexpr uint32_t WAVE_LDS = (2 * BIG_LDS + BUF_CAP) / 16; // P2 entries of the workgroup's LDS per wave in the short-slice role
+static_assert(WAVE_LDS >= 4 * 64 && WAVE_LDS >= 2 * HULL_LDS, "four rows of 64 points, or one hull of HULL_LDS vertices with its normals");
 // (8 waves per SIMD = two workgroups per CU: without the attribute the block role's 106 SGPRs allow seven, i.e. ONE workgroup)
 __global__ __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_slice_hulls(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice,
@@ -843,8 +1030,11 @@ __global__ __launch_bounds__(BIG_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
 		slice_hull_block(s_mem, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want, slice_off, big_list, big_count, spill, areas, cp);
 	} else {
 		const uint32_t w = threadIdx.x >> 6;
-		slice_hull_wave(s_mem + w * 2u * HULL_LDS, (blockIdx.x - big_max) * 16u + w, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want,
-		                slice_off, spill, areas, cp);
+		P2 *const mine = s_mem + w * WAVE_LDS; // the wave's share: four rows' points first, a long slice's hull and normals after
+		const uint32_t t0 = ((blockIdx.x - big_max) * 16u + w) * 4u;
+		const uint64_t left = slice_hulls_rows(mine, t0, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want, slice_off, areas, cp);
+		for (uint32_t r = 0; r < 4u; ++r)
+			if ((left >> (16u * r)) & 1ull) slice_hull_wave(mine, t0 + r, xyz, order, sorted_seg, sorted_slice, task_start, n_tasks, n, cls, want, slice_off, spill, areas, cp);
 	}
 }
 
@@ -1112,7 +1302,7 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	// 3. get_size_areas over all points -> SegmentInformation::new -> classification
 	TREEE_HIP(hipMemsetAsync(d_areas, 0, ((size_t)total_slices + 1) * 4, st)); // a slice without points has area 0.0
 	if (n_tasks)
-		hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 16)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
+		hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 64)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
 		                   nullptr, 0u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_areas, CrownPass{nullptr, nullptr, nullptr, nullptr, nullptr});
 	hipLaunchKernelGGL(k_seg_info, dim3(gs), dim3(256), 0, st, d_areas, d_sloff, d_nsl, d_seg_min, d_seg_max, nseg, d_seg_info);
 	if (n && d_cls) hipLaunchKernelGGL(k_classify, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, n, d_seg_max, d_seg_info, d_cls);
@@ -1124,7 +1314,7 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 			// the crown points' slice areas: one slice per segment needs its hull built again, the others are copies or 0.0 (CrownPass)
 			TREEE_TRY(ctx->alloc_t((size_t)total_slices + 1, &d_crown));
 			TREEE_HIP(hipMemsetAsync(d_crown, 0, ((size_t)total_slices + 1) * 4, st));
-			hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 16)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
+			hipLaunchKernelGGL(k_slice_hulls, dim3(big_grid + div_up(n_tasks, 64)), dim3(BIG_THREADS), 0, st, d_xyz, d_order, d_segF, d_sliceF, d_task_start, n_tasks, n,
 			                   d_cls, 2u, d_sloff, d_big, d_nbig, big_grid, d_spill, d_crown, CrownPass{d_seg_min, d_seg_max, d_seg_info, d_nsl, d_areas});
 			hipLaunchKernelGGL(k_seg_expansion, dim3(gs), dim3(256), 0, st, d_crown, d_sloff, d_nsl, d_seg_min, d_seg_info, nseg);
 		}
