@@ -82,6 +82,33 @@ __global__ __launch_bounds__(256) void k_init_aabb(uint32_t *__restrict__ aabb, 
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i < nseg * 6u) aabb[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u; // [s][0..2] = min (ordered image), [3..5] = max
 }
+// Round 4: the extremes straight from the cloud as it lies, no sort.  A value is sent (atomicMin / atomicMax on the ordered image)
+// only if it beats what the segment's word already holds, and the kernel runs three times -- every 3 001st point, every 61st,
+// every point -- so that by the time the half million threads of a full launch read those words they hold a sample's extremes
+// and almost nothing is left to send (a segment's running extreme over randomly ordered points improves ~ln(n) times; without
+// the samples every thread resident at launch sees the initial word and the ground's six words serialise them: the 2.5 ms
+// above).  `present` marks the segments that have a point (an empty segment is (0, 0, 0), calculations.rs:135-136).
+__global__ __launch_bounds__(256) void k_seg_aabb_direct(const float *__restrict__ xyz, const uint32_t *__restrict__ seg, uint32_t n, uint32_t nseg,
+                                                          uint32_t stride, uint32_t *aabb, uint32_t *present) {
+	const uint64_t i64 = (uint64_t)(blockIdx.x * 256u + threadIdx.x) * stride;
+	if (i64 >= n) return;
+	const uint32_t i = (uint32_t)i64, sg = seg[i];
+	if (sg >= nseg) return; // (reported by k_check_segments; nothing is indexed with it)
+	if (present[sg] == 0u) present[sg] = 1u;
+	// plain loads: a copy in the CU's L1 is at worst as old as this launch, i.e. holds the previous launch's sample -- an older
+	// value only means an atomic that was not needed (through the L2 -- volatile -- the six reads per point were 1.0 ms)
+	const uint2 *row = (const uint2 *)(aabb + (size_t)sg * 6u); // 24-byte rows: 8-byte aligned
+	const uint2 r0 = row[0], r1 = row[1], r2 = row[2];
+	const uint32_t cur[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		const float v = xyz[3ull * i + d];
+		if (v != v) continue; // f32::min / f32::max drop a NaN operand
+		const uint32_t o = f2ord(v);
+		if (o < cur[d]) atomicMin(&aabb[(size_t)sg * 6u + d], o);
+		if (o > cur[3 + d]) atomicMax(&aabb[(size_t)sg * 6u + 3u + d], o);
+	}
+}
 __global__ __launch_bounds__(256) void k_tile_aabb(const float *__restrict__ xyz, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ sorted_seg,
                                                     uint32_t n, uint32_t *__restrict__ aabb, uint32_t *__restrict__ tiles /* [n_tiles][8]: 6 extremes, segment, pad */) {
 	const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -169,14 +196,18 @@ __global__ __launch_bounds__(256) void k_seg_aabb(const uint32_t *__restrict__ t
 		}
 	}
 }
+__global__ __launch_bounds__(256) void k_present_from_starts(const uint32_t *__restrict__ start, uint32_t nseg, uint32_t *__restrict__ present) {
+	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+	if (s < nseg) present[s] = start[s + 1] != start[s] ? 1u : 0u;
+}
 // decode; an empty segment is (0, 0, 0) (calculations.rs:135-136), a segment whose every value along an axis is NaN keeps NaN
 // (min(NaN, NaN)); slice count of the segment (calculations.rs:217, 435)
-__global__ __launch_bounds__(256) void k_seg_finish_aabb(const uint32_t *__restrict__ aabb, const uint32_t *__restrict__ start, uint32_t nseg,
+__global__ __launch_bounds__(256) void k_seg_finish_aabb(const uint32_t *__restrict__ aabb, const uint32_t *__restrict__ present, uint32_t nseg,
                                                           float *__restrict__ seg_min, float *__restrict__ seg_max, uint32_t *__restrict__ n_slices,
                                                           uint32_t *__restrict__ err) {
 	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
 	if (s >= nseg) return;
-	const bool empty = start[s + 1] == start[s];
+	const bool empty = present[s] == 0u;
 	float mn[3], mx[3];
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
@@ -1141,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_init_i32(int32_t *__restrict__ p, uint3
 	if (i < n) p[i] = v;
 }
 __global__ __launch_bounds__(256) void k_seg_max_expansion(const float *__restrict__ expansion, const uint32_t *__restrict__ seg, uint32_t n,
-                                                            uint32_t stride, int32_t *__restrict__ best) {
+                                                            uint32_t stride, int32_t *best /* read plainly: an L1 copy is at worst the previous launch's sample */) {
 	const uint64_t i64 = (uint64_t)(blockIdx.x * 256u + threadIdx.x) * stride;
 	const uint32_t i = i64 < n ? (uint32_t)i64 : n;
 	// max_by(total_cmp): equal keys are identical bits.  The stored maximum only grows, so a value that does not beat even a
@@ -1158,10 +1189,10 @@ __global__ __launch_bounds__(256) void k_seg_max_expansion(const float *__restri
 	if (__ballot(live && sg != sg0) == 0ull && sg0 != 0xFFFFFFFFu) { // (lane 0 is live whenever any lane is: i ascends with the lane)
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) key = max(key, __shfl_xor(key, o, 64));
-		if ((threadIdx.x & 63u) == 0u && key > *(volatile const int32_t *)&best[sg0]) atomicMax(&best[sg0], key);
+		if ((threadIdx.x & 63u) == 0u && key > best[sg0]) atomicMax(&best[sg0], key);
 		return;
 	}
-	if (!live || key <= *(volatile const int32_t *)&best[sg]) return;
+	if (!live || key <= best[sg]) return;
 	atomicMax(&best[sg], key);
 }
 __device__ __forceinline__ uint32_t map_to_u32(float v) { // calculations.rs:455-457 (saturating cast, NaN -> 0)
@@ -1212,35 +1243,48 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	uint32_t *d_total = nullptr;
 	const size_t cnt = n ? n : 1;
 	TREEE_TRY(ctx->alloc_t(4, &d_err));
-	TREEE_TRY(ctx->alloc_t(cnt, &d_seg_sorted));
-	TREEE_TRY(ctx->alloc_t(cnt, &d_perm1));
-	TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_start));
 	TREEE_TRY(ctx->alloc_t((size_t)nseg * 6, &d_aabb));
 	TREEE_TRY(ctx->alloc_t(nseg, &d_nsl));
 	TREEE_TRY(ctx->alloc_t(nseg, &d_sloff));
 	TREEE_TRY(ctx->alloc_t(4, &d_total));
 	TREEE_HIP(hipMemsetAsync(d_err, 0, 16, st));
 	const int sbits = bits_for(nseg);
-	// 1. min / max of every segment (SegmentData::new): segment order, wave-aggregated atomics
+	// 1. min / max of every segment (SegmentData::new)
 	if (n) hipLaunchKernelGGL(k_check_segments, dim3(gn), dim3(256), 0, st, d_seg, n, nseg, d_err);
 	hipLaunchKernelGGL(k_init_aabb, dim3(div_up((uint64_t)nseg * 6, 256)), dim3(256), 0, st, d_aabb, nseg);
 	TREEE_LAUNCH_CHECK();
-	// (an id >= n_segments is reported below; the sort only looks at the low bits, the clamp keeps the kernels in range)
-	TREEE_TRY(sort_pairs_dev(ctx, d_seg, nullptr, n, sbits, d_seg_sorted, d_perm1));
+	uint32_t *d_present = nullptr; // [s] != 0: the segment has a point
+	TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_present));
+	static const bool sorted_aabb = getenv("TREEE_CALC_SORTED_AABB") != nullptr; // A/B and test hook: rounds 2-3's way
+	if (!sorted_aabb) {
+		// straight from the cloud as it lies: two samples, then every point (k_seg_aabb_direct); 1.15 -> 0.3 ms per 15 M points
+		TREEE_HIP(hipMemsetAsync(d_present, 0, ((size_t)nseg + 1) * 4, st));
+		for (uint32_t stride : {3001u, 61u, 1u})
+			if (n && (stride == 1u || n >= 64u * stride))
+				hipLaunchKernelGGL(k_seg_aabb_direct, dim3(div_up(div_up(n, stride), 256)), dim3(256), 0, st, d_xyz, d_seg, n, nseg, stride, d_aabb, d_present);
+		TREEE_LAUNCH_CHECK();
+	}
 	{ // ids beyond the range would index past the per-segment arrays: stop here if any
 		TREEE_HIP(hipMemcpyAsync(ctx->h_scalars, d_err, 4, hipMemcpyDeviceToHost, st));
 		TREEE_HIP(hipStreamSynchronize(st));
 		if (ctx->h_scalars[0] & 1u) return set_err(TREEE_ERR_INVALID, "segment id >= n_segments (%u)", nseg);
 	}
-	hipLaunchKernelGGL(k_starts, dim3(div_up((uint64_t)nseg + 1, 256)), dim3(256), 0, st, d_seg_sorted, n, nseg, d_start);
-	if (n) {
-		const uint32_t n_tiles = div_up(n, AABB_TILE);
-		uint32_t *d_tiles = nullptr;
-		TREEE_TRY(ctx->alloc_t((size_t)n_tiles * 8, &d_tiles));
-		hipLaunchKernelGGL(k_tile_aabb, dim3(div_up(n_tiles, 4)), dim3(256), 0, st, d_xyz, d_perm1, d_seg_sorted, n, d_aabb, d_tiles);
-		hipLaunchKernelGGL(k_seg_aabb, dim3(div_up(nseg, 4)), dim3(256), 0, st, d_tiles, d_start, nseg, d_aabb);
+	if (sorted_aabb) { // segment order (a sort), a tile's extremes per wave, a wave per segment over its tiles
+		TREEE_TRY(ctx->alloc_t(cnt, &d_seg_sorted));
+		TREEE_TRY(ctx->alloc_t(cnt, &d_perm1));
+		TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_start));
+		TREEE_TRY(sort_pairs_dev(ctx, d_seg, nullptr, n, sbits, d_seg_sorted, d_perm1));
+		hipLaunchKernelGGL(k_starts, dim3(div_up((uint64_t)nseg + 1, 256)), dim3(256), 0, st, d_seg_sorted, n, nseg, d_start);
+		if (n) {
+			const uint32_t n_tiles = div_up(n, AABB_TILE);
+			uint32_t *d_tiles = nullptr;
+			TREEE_TRY(ctx->alloc_t((size_t)n_tiles * 8, &d_tiles));
+			hipLaunchKernelGGL(k_tile_aabb, dim3(div_up(n_tiles, 4)), dim3(256), 0, st, d_xyz, d_perm1, d_seg_sorted, n, d_aabb, d_tiles);
+			hipLaunchKernelGGL(k_seg_aabb, dim3(div_up(nseg, 4)), dim3(256), 0, st, d_tiles, d_start, nseg, d_aabb);
+		}
+		hipLaunchKernelGGL(k_present_from_starts, dim3(gs), dim3(256), 0, st, d_start, nseg, d_present);
 	}
-	hipLaunchKernelGGL(k_seg_finish_aabb, dim3(gs), dim3(256), 0, st, d_aabb, d_start, nseg, d_seg_min, d_seg_max, d_nsl, d_err);
+	hipLaunchKernelGGL(k_seg_finish_aabb, dim3(gs), dim3(256), 0, st, d_aabb, d_present, nseg, d_seg_min, d_seg_max, d_nsl, d_err);
 	TREEE_LAUNCH_CHECK();
 	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_nsl, d_sloff, nseg, d_total));
 	// 2. final order = (segment, slice, input order): stable sort by slice, then by segment
