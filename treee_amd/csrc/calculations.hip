@@ -56,33 +56,16 @@ __global__ __launch_bounds__(256) void k_check_segments(const uint32_t *__restri
 }
 
 // start[s] = first position of segment s in the segment-sorted order, start[nseg] = n
-__global__ __launch_bounds__(256) void k_starts(const uint32_t *__restrict__ sorted_seg, uint32_t n, uint32_t nseg, uint32_t *__restrict__ start) {
-	const uint32_t sg = blockIdx.x * 256u + threadIdx.x;
-	if (sg > nseg) return;
-	uint32_t lo = 0, hi = n;
-	while (lo < hi) {
-		const uint32_t mid = lo + ((hi - lo) >> 1);
-		if (sorted_seg[mid] < sg)
-			lo = mid + 1;
-		else
-			hi = mid;
-	}
-	start[sg] = lo;
-}
-
 // ---- SegmentData::new, min / max (calculations.rs:135-147) --------------------------------------------------
 // f32::min / f32::max drop a NaN operand, so the result is the extreme of the non-NaN values: an order-independent
-// reduction.  Points come in segment order.  Pass 1: every wave reduces a tile of 256 consecutive points; a tile inside
-// one segment (nearly all) stores its six extremes without any atomic, a tile that straddles a boundary lets its lanes
-// update the segments' words directly.  Pass 2: one wave per segment folds the tiles inside its range into those
-// words.  (Atomics from every wave piled up: the first ~8 000 resident waves of a plot's ground segment all saw the
-// initial values and queued on six words -- 2.5 ms.)
-constexpr uint32_t AABB_TILE = 256;
+// reduction over ordered integer images of the floats.  (Rounds 2-3: the points sorted by segment, a tile's extremes per
+// wave through a 12-byte gather, a wave per segment over its tiles -- 1.15 ms per 15 M points; plain atomics from every
+// wave had piled up on a ground segment's six words: 2.5 ms.)
 __global__ __launch_bounds__(256) void k_init_aabb(uint32_t *__restrict__ aabb, uint32_t nseg) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i < nseg * 6u) aabb[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u; // [s][0..2] = min (ordered image), [3..5] = max
 }
-// Round 4: the extremes straight from the cloud as it lies, no sort.  A value is sent (atomicMin / atomicMax on the ordered image)
+// The extremes straight from the cloud as it lies, no sort.  A value is sent (atomicMin / atomicMax on the ordered image)
 // only if it beats what the segment's word already holds, and the kernel runs three times -- every 3 001st point, every 61st,
 // every point -- so that by the time the half million threads of a full launch read those words they hold a sample's extremes
 // and almost nothing is left to send (a segment's running extreme over randomly ordered points improves ~ln(n) times; without
@@ -109,97 +92,6 @@ __global__ __launch_bounds__(256) void k_seg_aabb_direct(const float *__restrict
 		if (o > cur[3 + d]) atomicMax(&aabb[(size_t)sg * 6u + 3u + d], o);
 	}
 }
-__global__ __launch_bounds__(256) void k_tile_aabb(const float *__restrict__ xyz, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ sorted_seg,
-                                                    uint32_t n, uint32_t *__restrict__ aabb, uint32_t *__restrict__ tiles /* [n_tiles][8]: 6 extremes, segment, pad */) {
-	const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-	const uint32_t base = tile * AABB_TILE;
-	if (base >= n) return;
-	uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-	const uint32_t last = (base + AABB_TILE <= n ? base + AABB_TILE : n) - 1u;
-	const uint32_t s_first = sorted_seg[base], s_last = sorted_seg[last];
-	const bool uniform = s_first == s_last; // sorted: the whole tile is one segment
-#pragma unroll
-	for (uint32_t k = 0; k < AABB_TILE / 64u; ++k) {
-		const uint32_t i = base + k * 64u + lane;
-		if (i >= n) continue;
-		const uint32_t o = perm[i];
-		uint32_t vlo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, vhi[3] = {0u, 0u, 0u};
-#pragma unroll
-		for (int d = 0; d < 3; ++d) {
-			const float v = xyz[3ull * o + d];
-			if (v == v) vlo[d] = vhi[d] = f2ord(v);
-		}
-		if (uniform) {
-#pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				lo[d] = min(lo[d], vlo[d]);
-				hi[d] = max(hi[d], vhi[d]);
-			}
-		} else { // a boundary tile (at most one per segment): straight into the segment's words
-			const uint32_t sg = sorted_seg[i];
-#pragma unroll
-			for (int d = 0; d < 3; ++d) {
-				if (vlo[d] != 0xFFFFFFFFu) atomicMin(&aabb[sg * 6u + d], vlo[d]);
-				if (vhi[d] != 0u) atomicMax(&aabb[sg * 6u + 3u + d], vhi[d]);
-			}
-		}
-	}
-	if (uniform) {
-#pragma unroll
-		for (int d = 0; d < 3; ++d)
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) {
-				lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o, 64));
-				hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o, 64));
-			}
-	}
-	if (lane == 0) {
-		uint32_t *t = tiles + (size_t)tile * 8u;
-		t[0] = lo[0];
-		t[1] = lo[1];
-		t[2] = lo[2];
-		t[3] = hi[0];
-		t[4] = hi[1];
-		t[5] = hi[2];
-		t[6] = uniform ? s_first : 0xFFFFFFFFu; // boundary tiles are already accounted for
-	}
-}
-// one wave per segment: the tiles that lie inside [start[s], start[s + 1]) and belong to it
-__global__ __launch_bounds__(256) void k_seg_aabb(const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ start, uint32_t nseg,
-                                                   uint32_t *__restrict__ aabb) {
-	const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-	if (s >= nseg) return;
-	const uint32_t b = start[s], e = start[s + 1u];
-	if (e == b) return;
-	uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-	for (uint32_t t = b / AABB_TILE + lane; t <= (e - 1u) / AABB_TILE; t += 64u) {
-		const uint32_t *q = tiles + (size_t)t * 8u;
-		if (q[6] != s) continue;
-#pragma unroll
-		for (int d = 0; d < 3; ++d) {
-			lo[d] = min(lo[d], q[d]);
-			hi[d] = max(hi[d], q[3 + d]);
-		}
-	}
-#pragma unroll
-	for (int d = 0; d < 3; ++d)
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
-			lo[d] = min(lo[d], (uint32_t)__shfl_xor((int)lo[d], o, 64));
-			hi[d] = max(hi[d], (uint32_t)__shfl_xor((int)hi[d], o, 64));
-		}
-	if (lane == 0) { // (the boundary tiles' atomics of pass 1 are complete: this kernel runs after it)
-#pragma unroll
-		for (int d = 0; d < 3; ++d) {
-			aabb[s * 6u + d] = min(aabb[s * 6u + d], lo[d]);
-			aabb[s * 6u + 3u + d] = max(aabb[s * 6u + 3u + d], hi[d]);
-		}
-	}
-}
-__global__ __launch_bounds__(256) void k_present_from_starts(const uint32_t *__restrict__ start, uint32_t nseg, uint32_t *__restrict__ present) {
-	const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-	if (s < nseg) present[s] = start[s + 1] != start[s] ? 1u : 0u;
-}
 // decode; an empty segment is (0, 0, 0) (calculations.rs:135-136), a segment whose every value along an axis is NaN keeps NaN
 // (min(NaN, NaN)); slice count of the segment (calculations.rs:217, 435)
 __global__ __launch_bounds__(256) void k_seg_finish_aabb(const uint32_t *__restrict__ aabb, const uint32_t *__restrict__ present, uint32_t nseg,
@@ -220,7 +112,9 @@ __global__ __launch_bounds__(256) void k_seg_finish_aabb(const uint32_t *__restr
 	const float height = mx[1] - mn[1];
 	const uint32_t raw = as_usize_u32(height / SLICE_WIDTH);
 	if (raw >= (1u << SLICE_BITS) - 1u) atomicOr(err, 2u);
-	n_slices[s] = (raw >= (1u << SLICE_BITS) - 1u ? (1u << SLICE_BITS) - 2u : raw) + 1u;
+	const uint32_t ns = (raw >= (1u << SLICE_BITS) - 1u ? (1u << SLICE_BITS) - 2u : raw) + 1u;
+	n_slices[s] = ns;
+	atomicMax(err + 1, ns); // (the width of the slice field in the sort key below)
 }
 
 // slice of every point, original order: ((pos.y - min) / SLICE_WIDTH) as usize (calculations.rs:442)
@@ -238,16 +132,18 @@ __global__ __launch_bounds__(256) void k_gather(const uint32_t *__restrict__ src
 	if (i < n) dst[i] = src[idx[i]];
 }
 // task = run of equal (segment, slice) in the final order; flag its first element
-__global__ __launch_bounds__(256) void k_join_keys(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ slice, uint32_t n, uint32_t *__restrict__ key) {
+__global__ __launch_bounds__(256) void k_join_keys(const uint32_t *__restrict__ seg, const uint32_t *__restrict__ slice, uint32_t n, uint32_t slbits,
+                                                    uint32_t *__restrict__ key) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i < n) key[i] = (seg[i] << SLICE_BITS) | slice[i]; // (slice < 2^SLICE_BITS - 1: k_seg_finish_aabb caps the count)
+	if (i < n) key[i] = (seg[i] << slbits) | slice[i]; // (slice < its segment's count <= the largest count < 2^slbits)
 }
-__global__ __launch_bounds__(256) void k_split_keys(const uint32_t *__restrict__ key, uint32_t n, uint32_t *__restrict__ seg, uint32_t *__restrict__ slice) {
+__global__ __launch_bounds__(256) void k_split_keys(const uint32_t *__restrict__ key, uint32_t n, uint32_t slbits, uint32_t *__restrict__ seg,
+                                                     uint32_t *__restrict__ slice) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t k = key[i];
-	seg[i] = k >> SLICE_BITS;
-	slice[i] = k & ((1u << SLICE_BITS) - 1u);
+	seg[i] = slbits < 32u ? k >> slbits : 0u;
+	slice[i] = slbits < 32u ? k & ((1u << slbits) - 1u) : k;
 }
 __global__ __launch_bounds__(256) void k_task_flags(const uint32_t *__restrict__ sorted_seg, const uint32_t *__restrict__ sorted_slice, uint32_t n,
                                                      uint32_t *__restrict__ flag) {
@@ -1239,7 +1135,7 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	TREEE_TRY(ctx->reset());
 	hipStream_t st = ctx->stream;
 	const uint32_t gn = div_up(n ? n : 1, 256), gs = div_up(nseg, 256);
-	uint32_t *d_err = nullptr, *d_seg_sorted = nullptr, *d_perm1 = nullptr, *d_start = nullptr, *d_aabb = nullptr, *d_nsl = nullptr, *d_sloff = nullptr;
+	uint32_t *d_err = nullptr, *d_aabb = nullptr, *d_nsl = nullptr, *d_sloff = nullptr;
 	uint32_t *d_total = nullptr;
 	const size_t cnt = n ? n : 1;
 	TREEE_TRY(ctx->alloc_t(4, &d_err));
@@ -1255,37 +1151,22 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	TREEE_LAUNCH_CHECK();
 	uint32_t *d_present = nullptr; // [s] != 0: the segment has a point
 	TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_present));
-	static const bool sorted_aabb = getenv("TREEE_CALC_SORTED_AABB") != nullptr; // A/B and test hook: rounds 2-3's way
-	if (!sorted_aabb) {
-		// straight from the cloud as it lies: two samples, then every point (k_seg_aabb_direct); 1.15 -> 0.3 ms per 15 M points
-		TREEE_HIP(hipMemsetAsync(d_present, 0, ((size_t)nseg + 1) * 4, st));
-		for (uint32_t stride : {3001u, 61u, 1u})
-			if (n && (stride == 1u || n >= 64u * stride))
-				hipLaunchKernelGGL(k_seg_aabb_direct, dim3(div_up(div_up(n, stride), 256)), dim3(256), 0, st, d_xyz, d_seg, n, nseg, stride, d_aabb, d_present);
-		TREEE_LAUNCH_CHECK();
-	}
-	{ // ids beyond the range would index past the per-segment arrays: stop here if any
-		TREEE_HIP(hipMemcpyAsync(ctx->h_scalars, d_err, 4, hipMemcpyDeviceToHost, st));
-		TREEE_HIP(hipStreamSynchronize(st));
-		if (ctx->h_scalars[0] & 1u) return set_err(TREEE_ERR_INVALID, "segment id >= n_segments (%u)", nseg);
-	}
-	if (sorted_aabb) { // segment order (a sort), a tile's extremes per wave, a wave per segment over its tiles
-		TREEE_TRY(ctx->alloc_t(cnt, &d_seg_sorted));
-		TREEE_TRY(ctx->alloc_t(cnt, &d_perm1));
-		TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_start));
-		TREEE_TRY(sort_pairs_dev(ctx, d_seg, nullptr, n, sbits, d_seg_sorted, d_perm1));
-		hipLaunchKernelGGL(k_starts, dim3(div_up((uint64_t)nseg + 1, 256)), dim3(256), 0, st, d_seg_sorted, n, nseg, d_start);
-		if (n) {
-			const uint32_t n_tiles = div_up(n, AABB_TILE);
-			uint32_t *d_tiles = nullptr;
-			TREEE_TRY(ctx->alloc_t((size_t)n_tiles * 8, &d_tiles));
-			hipLaunchKernelGGL(k_tile_aabb, dim3(div_up(n_tiles, 4)), dim3(256), 0, st, d_xyz, d_perm1, d_seg_sorted, n, d_aabb, d_tiles);
-			hipLaunchKernelGGL(k_seg_aabb, dim3(div_up(nseg, 4)), dim3(256), 0, st, d_tiles, d_start, nseg, d_aabb);
-		}
-		hipLaunchKernelGGL(k_present_from_starts, dim3(gs), dim3(256), 0, st, d_start, nseg, d_present);
-	}
+	// straight from the cloud as it lies: two samples, then every point (k_seg_aabb_direct)
+	TREEE_HIP(hipMemsetAsync(d_present, 0, ((size_t)nseg + 1) * 4, st));
+	for (uint32_t stride : {3001u, 61u, 1u})
+		if (n && (stride == 1u || n >= 64u * stride))
+			hipLaunchKernelGGL(k_seg_aabb_direct, dim3(div_up(div_up(n, stride), 256)), dim3(256), 0, st, d_xyz, d_seg, n, nseg, stride, d_aabb, d_present);
 	hipLaunchKernelGGL(k_seg_finish_aabb, dim3(gs), dim3(256), 0, st, d_aabb, d_present, nseg, d_seg_min, d_seg_max, d_nsl, d_err);
 	TREEE_LAUNCH_CHECK();
+	{ // first host round trip: ids beyond the range would index past the per-segment arrays (stop here if any); the largest
+	  // slice count of a segment sizes the sort key
+		TREEE_HIP(hipMemcpyAsync(ctx->h_scalars, d_err, 8, hipMemcpyDeviceToHost, st));
+		TREEE_HIP(hipStreamSynchronize(st));
+		if (ctx->h_scalars[0] & 1u) return set_err(TREEE_ERR_INVALID, "segment id >= n_segments (%u)", nseg);
+		if (ctx->h_scalars[0] & 2u)
+			return set_err(TREEE_ERR_UNSUPPORTED, "a segment is taller than %u slices of %.1f m", (1u << SLICE_BITS) - 2u, (double)SLICE_WIDTH);
+	}
+	const int slbits = bits_for(ctx->h_scalars[1]); // slice < the largest count < 2^slbits
 	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_nsl, d_sloff, nseg, d_total));
 	// 2. final order = (segment, slice, input order): stable sort by slice, then by segment
 	uint32_t *d_slice = nullptr, *d_slice_s = nullptr, *d_permA = nullptr, *d_segA = nullptr, *d_segF = nullptr, *d_order = nullptr, *d_sliceF = nullptr;
@@ -1304,15 +1185,15 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	if (n) {
 		hipLaunchKernelGGL(k_slice_index, dim3(gn), dim3(256), 0, st, d_xyz, d_seg, n, d_seg_min, d_nsl, d_slice);
 		TREEE_LAUNCH_CHECK();
-		if (sbits + (int)SLICE_BITS <= 32) {
-			// one stable sort by (segment << SLICE_BITS | slice) is the same permutation as a stable sort by slice followed by a
+		if (sbits + slbits <= 32) {
+			// one stable sort by (segment << slbits | slice) is the same permutation as a stable sort by slice followed by a
 			// stable sort by segment -- and leaves both keys in final order without the two gathers (0.5 ms of a 15 M-point cloud)
-			hipLaunchKernelGGL(k_join_keys, dim3(gn), dim3(256), 0, st, d_seg, d_slice, n, d_segA);
+			hipLaunchKernelGGL(k_join_keys, dim3(gn), dim3(256), 0, st, d_seg, d_slice, n, (uint32_t)slbits, d_segA);
 			TREEE_LAUNCH_CHECK();
-			TREEE_TRY(sort_pairs_dev(ctx, d_segA, nullptr, n, sbits + (int)SLICE_BITS, d_slice_s, d_order));
-			hipLaunchKernelGGL(k_split_keys, dim3(gn), dim3(256), 0, st, d_slice_s, n, d_segF, d_sliceF);
-		} else { // more than 65 536 segments: two sorts
-			TREEE_TRY(sort_pairs_dev(ctx, d_slice, nullptr, n, (int)SLICE_BITS, d_slice_s, d_permA));
+			TREEE_TRY(sort_pairs_dev(ctx, d_segA, nullptr, n, sbits + slbits, d_slice_s, d_order));
+			hipLaunchKernelGGL(k_split_keys, dim3(gn), dim3(256), 0, st, d_slice_s, n, (uint32_t)slbits, d_segF, d_sliceF);
+		} else { // (millions of segments AND thousands of slices: two sorts)
+			TREEE_TRY(sort_pairs_dev(ctx, d_slice, nullptr, n, slbits, d_slice_s, d_permA));
 			hipLaunchKernelGGL(k_gather, dim3(gn), dim3(256), 0, st, d_seg, d_permA, n, d_segA);
 			TREEE_LAUNCH_CHECK();
 			TREEE_TRY(sort_pairs_dev(ctx, d_segA, d_permA, n, sbits, d_segF, d_order));
