@@ -175,6 +175,10 @@ __device__ __forceinline__ P2 edge_normal(P2 a, P2 b) {
 	const float norm = sqrtf(ox * ox + oy * oy);
 	return P2{ox / norm, oy / norm};
 }
+__device__ __forceinline__ bool unit_length(P2 n) { // (false for NaN, infinite and zero "normals": see slice_hull_block)
+	const float l2 = n.x * n.x + n.y * n.y;
+	return l2 > 0.5f && l2 < 2.0f;
+}
 __device__ __forceinline__ bool edge_outside(P2 a, P2 nrm, P2 p) {
 	const float fx = p.x - a.x, fy = p.y - a.y;
 	const float dist = nrm.x * fx + nrm.y * fy;
@@ -581,7 +585,15 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 //     TWO runs, and the reference's splice (last start, last end: segmenting.rs:356-380) then cuts a piece of the hull off;
 //     points dropped earlier could matter again.  Every insertion therefore counts its runs, and a slice that sees such an
 //     insertion is done AGAIN from its first point with the filter off (bit for bit the reference either way).
-constexpr uint32_t COARSE = 12, BUF_CAP = 2048, BUF_GO = 1024, FILL_PPT = 2;
+//   * ... and while every edge has a unit normal.  An edge whose normal is NaN or zero -- a vertex at infinity, two equal
+//     consecutive vertices -- never calls a point outside: the polygon is no convex polygon any more, and a later insertion
+//     beside such an edge (ONE run, nothing to count) can turn a new edge's outside towards the old interior.  Found by the
+//     soak (tests/soak_calculations.py, seed 531: a point at -inf in a 20 000-point slice): a hull that gets such an edge
+//     sends its slice to the second attempt too.
+#ifndef TREEE_FILL_PPT
+#define TREEE_FILL_PPT 2
+#endif
+constexpr uint32_t COARSE = 12, BUF_CAP = 2048, BUF_GO = 1024, FILL_PPT = TREEE_FILL_PPT;
 constexpr float COARSE_MARGIN = 6.103515625e-05f; // 2^-14
 __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF_CAP entries */, const float *__restrict__ xyz,
                                                  const uint32_t *__restrict__ order, const uint32_t *__restrict__ sorted_seg,
@@ -608,11 +620,22 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 		N = s_hull + BIG_LDS;
 		uint32_t cap = BIG_LDS;
 		m = 0;
+#ifdef TREEE_TEST_FORCE_SECOND_ATTEMPT // (validation build: every big slice is done twice, the second time without filter or drops)
+		if (tid == 0) s_two_runs = 1u;
+#else
 		if (tid == 0) s_two_runs = 0u;
+#endif
+		// (a normal that is not a unit vector -- NaN or zero: a vertex at infinity, two equal consecutive vertices, an edge too long
+		// for its squared length -- is an edge that never calls a point outside: the hull is then no convex polygon any more, an insertion next to such an edge can turn an edge's outside
+		// towards the old interior, and points dropped before would matter again: the slice is done again without drops)
 		auto normals = [&]() __attribute__((always_inline)) {
 			for (uint32_t c = 0; c < m; c += BIG_THREADS) {
 				const uint32_t j = c + tid;
-				if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+				if (j < m) {
+					const P2 nn = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+					N[j] = nn;
+					if (!unit_length(nn)) s_two_runs = 1u;
+				}
 			}
 			__syncthreads();
 		};
@@ -661,7 +684,11 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 		auto wave_normals = [&]() __attribute__((always_inline)) {
 			for (uint32_t c = 0; c < m; c += 64u) {
 				const uint32_t j = c + tid;
-				if (j < m) N[j] = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+				if (j < m) {
+					const P2 nn = edge_normal(H[j], H[j + 1u < m ? j + 1u : 0u]);
+					N[j] = nn;
+					if (!unit_length(nn)) s_two_runs = 1u; // (see `normals`)
+				}
 			}
 			wave_sync();
 		};
@@ -787,7 +814,11 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 				// in parallel, against the real hull with the filter's margin -- a point inside by the margin is inside every later
 				// hull (see above) and is dropped --, and the few that remain are inserted one by one by wave 0, an edge per lane.
 				// (Not on the second attempt: there a hull has been cut, and nothing may be dropped.)
+#ifdef TREEE_TEST_NO_RESIDUE
+				if (false) {
+#else
 				if (filter_on && m != 0u && m <= 64u && cap == BIG_LDS) {
+#endif
 					bool rest = pending;
 					if (pending) {
 						const float mag = fabsf(p.x) + fabsf(p.y);
@@ -798,6 +829,9 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 							inside = inside && nv.x * fx + nv.y * fy <= -COARSE_MARGIN * (mag + fabsf(hv.x) + fabsf(hv.y));
 						}
 						rest = !inside; // (NaN anywhere compares false: the point stays)
+#ifdef TREEE_TEST_RESIDUE_KEEPS_ALL
+						rest = true;
+#endif
 					}
 					const uint64_t km = __ballot(rest);
 					if ((tid & 63u) == 0u) s_wcnt[0][tid >> 6] = (uint32_t)__popcll(km);
@@ -882,9 +916,6 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 					const uint32_t s0 = s_se[0], e0 = s_se[1];
 					const P2 np = s_p;
 					if (tid == 0 && m != 0 && s_se[2] > 1u) s_two_runs = 1u;
-#ifdef TREEE_TEST_FORCE_SECOND_ATTEMPT // (validation build: every big slice is done twice, the second time without the filter)
-					if (tid == 0) s_two_runs = 1u;
-#endif
 					// (new size first, as in slice_hull_wave: the move to HBM happens before any write of either branch)
 					if (m != 0 && (e0 < s0 ? s0 - e0 + 2u : s0 + 2u + (m - e0)) > cap) {
 						for (uint32_t c = 0; c < m; c += BIG_THREADS)
