@@ -1,6 +1,7 @@
 """Soak of the Calculations phase against the CPU restatement (not collected by pytest: run on a GPU box):
     python tests/soak_calculations.py [first_seed] [count]
-runs the seeded generators of test_long_slices_fuzz_vs_oracle and test_segments_calculate_fuzz_vs_oracle for `count` further seeds."""
+runs the seeded generators of test_long_slices_fuzz_vs_oracle, test_segments_calculate_fuzz_vs_oracle and
+test_long_slices_with_points_at_infinity for `count` further seeds.  (Seed 531 of the first found the hull-with-a-NaN-normal case.)"""
 import os
 import sys
 import time
@@ -21,6 +22,7 @@ t0 = time.time()
 for seed in range(first, first + count):
     P.test_long_slices_fuzz_vs_oracle(T, O, seed)
     P.test_segments_calculate_fuzz_vs_oracle(T, O, seed)
+    P.test_long_slices_with_points_at_infinity(T, O, seed)
     if (seed - first) % 10 == 9:
         print(f"seed {seed}: ok ({time.time() - t0:.0f} s)", flush=True)
-print(f"{count} seeds of both generators: all bit-identical to the CPU restatement")
+print(f"{count} seeds of the three generators: all bit-identical to the CPU restatement")
