@@ -814,11 +814,7 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 				// in parallel, against the real hull with the filter's margin -- a point inside by the margin is inside every later
 				// hull (see above) and is dropped --, and the few that remain are inserted one by one by wave 0, an edge per lane.
 				// (Not on the second attempt: there a hull has been cut, and nothing may be dropped.)
-#ifdef TREEE_TEST_NO_RESIDUE
-				if (false) {
-#else
 				if (filter_on && m != 0u && m <= 64u && cap == BIG_LDS) {
-#endif
 					bool rest = pending;
 					if (pending) {
 						const float mag = fabsf(p.x) + fabsf(p.y);
@@ -829,7 +825,7 @@ __device__ __forceinline__ void slice_hull_block(P2 *s_hull /* 2 * BIG_LDS + BUF
 							inside = inside && nv.x * fx + nv.y * fy <= -COARSE_MARGIN * (mag + fabsf(hv.x) + fabsf(hv.y));
 						}
 						rest = !inside; // (NaN anywhere compares false: the point stays)
-#ifdef TREEE_TEST_RESIDUE_KEEPS_ALL
+#ifdef TREEE_TEST_RESIDUE_KEEPS_ALL // (validation build: the one-by-one path without its drops; how seed 531's cause was found)
 						rest = true;
 #endif
 					}
