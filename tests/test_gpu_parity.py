@@ -2107,7 +2107,7 @@ def test_long_slices_with_points_at_infinity(T, oracle, seed):
     _check_segments_against_oracle(T, oracle, pts, seg, 1, device=bool(seed & 1))
 
 
-@pytest.mark.parametrize("seed", list(range(8)) + [531])  # (531: found by tests/soak_calculations.py -- a point at -inf enters a long slice's hull)
+@pytest.mark.parametrize("seed", list(range(8)) + [531])  # (531: found by tests/soak_calculations_seeds.py -- a point at -inf enters a long slice's hull)
 def test_long_slices_fuzz_vs_oracle(T, oracle, seed):
     """the workgroup-per-slice path (>= 2 048 points in a 0.1 m slice: point-by-point start, coarse-polygon filter, compaction,
     second attempt) on seeded slices of 2 500 ... 60 000 points and very different hulls -- discs and Gaussians (a few dozen

@@ -588,7 +588,7 @@ __device__ __forceinline__ void slice_hull_wave(P2 *lds /* this wave's 2 * HULL_
 //   * ... and while every edge has a unit normal.  An edge whose normal is NaN or zero -- a vertex at infinity, two equal
 //     consecutive vertices -- never calls a point outside: the polygon is no convex polygon any more, and a later insertion
 //     beside such an edge (ONE run, nothing to count) can turn a new edge's outside towards the old interior.  Found by the
-//     soak (tests/soak_calculations.py, seed 531: a point at -inf in a 20 000-point slice): a hull that gets such an edge
+//     soak (tests/soak_calculations_seeds.py, seed 531: a point at -inf in a 20 000-point slice): a hull that gets such an edge
 //     sends its slice to the second attempt too.
 #ifndef TREEE_FILL_PPT
 #define TREEE_FILL_PPT 2
