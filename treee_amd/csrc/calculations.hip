@@ -65,15 +65,22 @@ __global__ __launch_bounds__(256) void k_init_aabb(uint32_t *__restrict__ aabb, 
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i < nseg * 6u) aabb[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u; // [s][0..2] = min (ordered image), [3..5] = max
 }
+#ifndef TREEE_AABB_STRIDES // (A/B hook: the sampling ladder)
+#define TREEE_AABB_STRIDES 50021u, 3001u, 251u, 16u, 1u
+#define TREEE_AABB_RUNS 1u, 1u, 1u, 64u, 1u
+#endif
 // The extremes straight from the cloud as it lies, no sort.  A value is sent (atomicMin / atomicMax on the ordered image)
-// only if it beats what the segment's word already holds, and the kernel runs three times -- every 3 001st point, every 61st,
-// every point -- so that by the time the half million threads of a full launch read those words they hold a sample's extremes
+// only if it beats what the segment's word already holds, and the kernel runs as a ladder of samples -- every 50 021st point,
+// every 3 001st, every 251st, a sixteenth of the cloud in runs of 64, every point -- so that by the time the half million threads of a full launch read those words they hold a sample's extremes
 // and almost nothing is left to send (a segment's running extreme over randomly ordered points improves ~ln(n) times; without
 // the samples every thread resident at launch sees the initial word and the ground's six words serialise them: the 2.5 ms
 // above).  `present` marks the segments that have a point (an empty segment is (0, 0, 0), calculations.rs:135-136).
 __global__ __launch_bounds__(256) void k_seg_aabb_direct(const float *__restrict__ xyz, const uint32_t *__restrict__ seg, uint32_t n, uint32_t nseg,
-                                                          uint32_t stride, uint32_t *aabb, uint32_t *present) {
-	const uint64_t i64 = (uint64_t)(blockIdx.x * 256u + threadIdx.x) * stride;
+                                                          uint32_t stride, uint32_t run, uint32_t *aabb, uint32_t *present) {
+	// (the sample: runs of `run` consecutive points, one run every `stride` runs -- single points for the sparse levels, runs of
+	// 64 for the dense one, whose reads then come in whole lines)
+	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+	const uint64_t i64 = (uint64_t)(t / run) * run * stride + t % run;
 	if (i64 >= n) return;
 	const uint32_t i = (uint32_t)i64, sg = seg[i];
 	if (sg >= nseg) return; // (reported by k_check_segments; nothing is indexed with it)
@@ -1180,9 +1187,15 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_present));
 	// straight from the cloud as it lies: two samples, then every point (k_seg_aabb_direct)
 	TREEE_HIP(hipMemsetAsync(d_present, 0, ((size_t)nseg + 1) * 4, st));
-	for (uint32_t stride : {3001u, 61u, 1u})
-		if (n && (stride == 1u || n >= 64u * stride))
-			hipLaunchKernelGGL(k_seg_aabb_direct, dim3(div_up(div_up(n, stride), 256)), dim3(256), 0, st, d_xyz, d_seg, n, nseg, stride, d_aabb, d_present);
+	{
+		const uint32_t strides[] = {TREEE_AABB_STRIDES}, runs[] = {TREEE_AABB_RUNS};
+		static_assert(sizeof(strides) == sizeof(runs), "one run length per level");
+		for (size_t l = 0; l < sizeof(strides) / sizeof(strides[0]); ++l) {
+			const uint32_t stride = strides[l], run = runs[l];
+			if (n && (stride == 1u || n >= 64ull * stride * run))
+				hipLaunchKernelGGL(k_seg_aabb_direct, dim3(div_up(div_up(n, stride) + run, 256)), dim3(256), 0, st, d_xyz, d_seg, n, nseg, stride, run, d_aabb, d_present);
+		}
+	}
 	hipLaunchKernelGGL(k_seg_finish_aabb, dim3(gs), dim3(256), 0, st, d_aabb, d_present, nseg, d_seg_min, d_seg_max, d_nsl, d_err);
 	TREEE_LAUNCH_CHECK();
 	{ // first host round trip: ids beyond the range would index past the per-segment arrays (stop here if any); the largest
