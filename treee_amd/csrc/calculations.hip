@@ -1306,9 +1306,9 @@ int32_t treee_display_values_dev(treee_ctx *ctx, const uint32_t *d_seg, uint64_t
 		// max_by(total_cmp).unwrap_or_default(): every queried segment has at least the querying point, so the start value
 		// (the smallest key of the total order) never survives where it is read
 		hipLaunchKernelGGL(k_init_i32, dim3(div_up(nseg, 256)), dim3(256), 0, ctx->stream, d_best, nseg, (int32_t)0x80000000);
-		constexpr uint32_t SAMPLE = 61;
-		if (n >= 65536u) hipLaunchKernelGGL(k_seg_max_expansion, dim3(div_up(div_up(n, SAMPLE), 256)), dim3(256), 0, ctx->stream, d_expansion, d_seg, n, SAMPLE, d_best);
-		hipLaunchKernelGGL(k_seg_max_expansion, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_expansion, d_seg, n, 1u, d_best);
+		for (uint32_t stride : {50021u, 3001u, 61u, 1u}) // (a ladder of samples, as for the segments' extremes: k_seg_aabb_direct)
+			if (stride == 1u || n >= 64ull * stride)
+				hipLaunchKernelGGL(k_seg_max_expansion, dim3(div_up(div_up(n, stride), 256)), dim3(256), 0, ctx->stream, d_expansion, d_seg, n, stride, d_best);
 	}
 	hipLaunchKernelGGL(k_display_values, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_seg, d_cls, d_curve, d_expansion, d_height, n, d_best, d_cls_val,
 	                   d_curve_val, d_exp_val, d_height_val);
