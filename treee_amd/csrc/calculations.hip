@@ -90,13 +90,18 @@ __global__ __launch_bounds__(256) void k_seg_aabb_direct(const float *__restrict
 	const uint2 *row = (const uint2 *)(aabb + (size_t)sg * 6u); // 24-byte rows: 8-byte aligned
 	const uint2 r0 = row[0], r1 = row[1], r2 = row[2];
 	const uint32_t cur[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+	uint32_t o[3], better = 0; // bit d: below the minimum read, bit 3 + d: above the maximum
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
 		const float v = xyz[3ull * i + d];
-		if (v != v) continue; // f32::min / f32::max drop a NaN operand
-		const uint32_t o = f2ord(v);
-		if (o < cur[d]) atomicMin(&aabb[(size_t)sg * 6u + d], o);
-		if (o > cur[3 + d]) atomicMax(&aabb[(size_t)sg * 6u + 3u + d], o);
+		o[d] = f2ord(v);
+		if (v == v) better |= (o[d] < cur[d] ? 1u << d : 0u) | (o[d] > cur[3 + d] ? 8u << d : 0u); // (f32::min / f32::max drop a NaN operand)
+	}
+	if (better == 0u) return; // (nearly every thread of the full launch: one branch, not six)
+#pragma unroll
+	for (int d = 0; d < 3; ++d) {
+		if (better & (1u << d)) atomicMin(&aabb[(size_t)sg * 6u + d], o[d]);
+		if (better & (8u << d)) atomicMax(&aabb[(size_t)sg * 6u + 3u + d], o[d]);
 	}
 }
 // decode; an empty segment is (0, 0, 0) (calculations.rs:135-136), a segment whose every value along an axis is NaN keeps NaN
