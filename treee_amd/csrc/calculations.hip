@@ -61,9 +61,10 @@ __global__ __launch_bounds__(256) void k_check_segments(const uint32_t *__restri
 // reduction over ordered integer images of the floats.  (Rounds 2-3: the points sorted by segment, a tile's extremes per
 // wave through a 12-byte gather, a wave per segment over its tiles -- 1.15 ms per 15 M points; plain atomics from every
 // wave had piled up on a ground segment's six words: 2.5 ms.)
+constexpr uint32_t AABB_ROW = 8; // words per segment in the table of extremes
 __global__ __launch_bounds__(256) void k_init_aabb(uint32_t *__restrict__ aabb, uint32_t nseg) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i < nseg * 6u) aabb[i] = (i % 6u) < 3u ? 0xFFFFFFFFu : 0u; // [s][0..2] = min (ordered image), [3..5] = max
+	if (i < nseg * AABB_ROW) aabb[i] = (i % AABB_ROW) < 3u ? 0xFFFFFFFFu : 0u; // [s][0..2] = min (ordered image), [3..5] = max, [6..7] pad
 }
 #ifndef TREEE_AABB_STRIDES // (A/B hook: the sampling ladder)
 #define TREEE_AABB_STRIDES 50021u, 3001u, 251u, 16u, 1u
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(256) void k_seg_aabb_direct(const float *__restrict
 	if (present[sg] == 0u) present[sg] = 1u;
 	// plain loads: a copy in the CU's L1 is at worst as old as this launch, i.e. holds the previous launch's sample -- an older
 	// value only means an atomic that was not needed (through the L2 -- volatile -- the six reads per point were 1.0 ms)
-	const uint2 *row = (const uint2 *)(aabb + (size_t)sg * 6u); // 24-byte rows: 8-byte aligned
-	const uint2 r0 = row[0], r1 = row[1], r2 = row[2];
-	const uint32_t cur[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+	const uint4 *row = (const uint4 *)(aabb + (size_t)sg * AABB_ROW); // 32-byte rows: two 16-byte gathers per point, not three of 8
+	const uint4 r0 = row[0], r1 = row[1];
+	const uint32_t cur[6] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y};
 	uint32_t o[3], better = 0; // bit d: below the minimum read, bit 3 + d: above the maximum
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(256) void k_seg_aabb_direct(const float *__restrict
 	if (better == 0u) return; // (nearly every thread of the full launch: one branch, not six)
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
-		if (better & (1u << d)) atomicMin(&aabb[(size_t)sg * 6u + d], o[d]);
-		if (better & (8u << d)) atomicMax(&aabb[(size_t)sg * 6u + 3u + d], o[d]);
+		if (better & (1u << d)) atomicMin(&aabb[(size_t)sg * AABB_ROW + d], o[d]);
+		if (better & (8u << d)) atomicMax(&aabb[(size_t)sg * AABB_ROW + 3u + d], o[d]);
 	}
 }
 // decode; an empty segment is (0, 0, 0) (calculations.rs:135-136), a segment whose every value along an axis is NaN keeps NaN
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_seg_finish_aabb(const uint32_t *__restr
 	float mn[3], mx[3];
 #pragma unroll
 	for (int d = 0; d < 3; ++d) {
-		const uint32_t a = aabb[s * 6u + d], b = aabb[s * 6u + 3u + d];
+		const uint32_t a = aabb[s * AABB_ROW + d], b = aabb[s * AABB_ROW + 3u + d];
 		mn[d] = empty ? 0.0f : (a == 0xFFFFFFFFu ? __uint_as_float(0x7FC00000u) : ord2f(a));
 		mx[d] = empty ? 0.0f : (b == 0u ? __uint_as_float(0x7FC00000u) : ord2f(b));
 		seg_min[s * 3u + d] = mn[d];
@@ -1178,7 +1179,7 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	uint32_t *d_total = nullptr;
 	const size_t cnt = n ? n : 1;
 	TREEE_TRY(ctx->alloc_t(4, &d_err));
-	TREEE_TRY(ctx->alloc_t((size_t)nseg * 6, &d_aabb));
+	TREEE_TRY(ctx->alloc_t((size_t)nseg * AABB_ROW, &d_aabb));
 	TREEE_TRY(ctx->alloc_t(nseg, &d_nsl));
 	TREEE_TRY(ctx->alloc_t(nseg, &d_sloff));
 	TREEE_TRY(ctx->alloc_t(4, &d_total));
@@ -1186,7 +1187,7 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 	const int sbits = bits_for(nseg);
 	// 1. min / max of every segment (SegmentData::new)
 	if (n) hipLaunchKernelGGL(k_check_segments, dim3(gn), dim3(256), 0, st, d_seg, n, nseg, d_err);
-	hipLaunchKernelGGL(k_init_aabb, dim3(div_up((uint64_t)nseg * 6, 256)), dim3(256), 0, st, d_aabb, nseg);
+	hipLaunchKernelGGL(k_init_aabb, dim3(div_up((uint64_t)nseg * AABB_ROW, 256)), dim3(256), 0, st, d_aabb, nseg);
 	TREEE_LAUNCH_CHECK();
 	uint32_t *d_present = nullptr; // [s] != 0: the segment has a point
 	TREEE_TRY(ctx->alloc_t((size_t)nseg + 1, &d_present));
