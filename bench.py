@@ -607,6 +607,13 @@ def calculations_stage(pts, seg, ctx, cpu=True):
         "calculate_ms": round(min(ts[1:]), 3),
         "display_values_ms": round(min(tv[1:]), 3),
         "Mpoints_per_s": round(n / (min(ts[1:]) * 1e-3) / 1e6, 1),
+        # against the HBM roofline on the phase's algorithmic bytes (16 B read -- xyz + segment id -- and 12 B
+        # written -- class, expansion, height -- per point; display values: 20 B read, 16 B written).  Small by construction: the
+        # phase is the reference's SEQUENTIAL hull insertion per slice, bound by instruction issue and dependent latency
+        "calculate_GBps": round(28 * n / (min(ts[1:]) * 1e-3) / 1e9, 1),
+        "calculate_frac": round(28 * n / (min(ts[1:]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "display_values_GBps": round(36 * n / (min(tv[1:]) * 1e-3) / 1e9, 1),
+        "display_values_frac": round(36 * n / (min(tv[1:]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
     }
     if cpu:
         from oracle import oracle as O
