@@ -658,7 +658,9 @@ def out_of_core_stage(dev, n, proj, tiles=67):
             b = base[i % len(base)]  # placed on a 9 x 8 grid through the LAS header offset
             yield stream.Tile(b.records, b.n, b.stride, b.scale, ((i % 9) * PLOT, (i // 9) * PLOT, 0.0), (4 * PLOT, 3.5 * PLOT, 0.0))
 
-    res = {"workload": f"{tiles} LAS tiles x {n} points from pinned host memory, 20 B records"}
+    res = {"workload": f"{tiles} LAS tiles x {n} points from pinned host memory, 20 B records",
+           "per_tile_mode": "octree_splat / octree_knn_splat: PER TILE, NO GHOST POINTS -- one octree per tile (its own cube), kNN inside a tile only "
+                            "(a point near a tile border sees one side); whole_cloud is the one-cloud result"}
     for name, k in (("octree_splat", 0), ("octree_knn_splat", K)):
         ts = stream.TileStream(dev, n, width=W, height=H, knn_k=k)
         ts.run(gen(3), view, proj, env)
@@ -669,6 +671,32 @@ def out_of_core_stage(dev, n, proj, tiles=67):
         ts.close()
         res[name] = {"points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1),
                      "pcie_GBps": round(r["points"] * 20 / dt / 1e9, 1)}
+    # configs[4] as ONE cloud: the same tiles decoded into one resident buffer (12 B x 1.005 G = 12 GB of HBM), then one sort /
+    # octree / LOD with one cube and global numbering, the kNN structure from that sort, curvature with neighbours across tile
+    # borders, one splat (stream.WholeCloudStream).  PCIe-inclusive wall time of the second of two runs.
+    try:
+        torch.cuda.empty_cache()
+        ws = stream.WholeCloudStream(dev, n * tiles, n, width=W, height=H, knn_k=K)
+        ws.run(gen(3), view, proj, env)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = ws.run(gen(tiles), view, proj, env)
+        dt = time.perf_counter() - t0
+        st = r["stages_ms"]
+        b_struct, b_knn = BYTES["keys_sort_octree_knn_structure"], BYTES["knn_curve"]
+        res["whole_cloud"] = {
+            "mode": r["mode"], "points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1),
+            "pcie_GBps_during_ingest": round(r["points"] * 20 / (st["ingest_decode"] * 1e-3) / 1e9, 1),
+            "stages_ms": {k: round(v, 2) for k, v in st.items()}, "octree_nodes": r["nodes"], "lod_entries": r["lod"], "cube_size_m": round(r["size"], 1),
+            "knn_curve_frac_of_hbm": round(b_knn * r["points"] / (st["knn_curve"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "structure_frac_of_hbm": round(b_struct * r["points"] / (st["sort_octree_knn_structure"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "hbm_in_use_GB": round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 1e9, 1),  # cloud + both structures + workspace, handles alive
+        }
+        ws.close()
+        del ws
+        torch.cuda.empty_cache()
+    except Exception as e:  # (a side measurement must not take the main line down)
+        res["whole_cloud"] = {"error": f"{type(e).__name__}: {e}"}
     # the same stream from LAZ tiles (configs[4] as BASELINE.json words it): decompressed on the host's threads, one tile
     # ahead of the GPU -- what bounds it is the host, as in the reference (laz.rs:134-160)
     import copy

@@ -18,8 +18,10 @@
  *     not synchronise unless documented
  *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails
  *     with TREEE_ERR_HIP
- *   - indices on the device are u32 (<= 2^32-2 points per shard); the host structs widen to
- *     u64 like Rust's usize
+ *   - indices on the device are u32 and a cloud (one shard) holds at most 2^31 - 1 points: every build
+ *     refuses more with TREEE_ERR_UNSUPPORTED (position arithmetic inside the kernels is 32-bit; the
+ *     largest cloud run is 1.005 G points, tests/test_gpu_parity.py::test_full_size_1g_whole_cloud_properties);
+ *     the host structs widen to u64 like Rust's usize
  *
  * Streams
  *   - a handle (treee_knn, treee_octree) is OWNED by the context that built it: its arrays come from
@@ -126,6 +128,18 @@ int32_t treee_knn_query_batch_dev(treee_ctx *ctx, const treee_knn *t, const floa
  * belongs to original point i */
 int32_t treee_knn_self_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
                            float *d_dist, uint32_t *d_index, uint32_t *d_counts);
+/* The same, and WHICH ROWS A DISTANCE TIE TOUCHES (d_tie_flags[n], one byte per original point; may be NULL):
+ *   bit 0  two of the row's k entries are equally far -- the reference's list holds the same points, possibly in another
+ *          order (best_set.rs:56-66 orders equal keys by heap mechanics), so sums over the list may differ in their last bits;
+ *   bit 1  the k-th entry and the next candidate behind it are equally far -- the reference keeps whichever its KD-tree
+ *          visited first (strict `<` at kd_tree.rs:114,125), this library the smaller (cell, index): the two lists may hold
+ *          DIFFERENT points there, and everything derived from the list (calculations.rs:332-368) may differ.
+ * A row with flag 0 has pairwise distinct distances up to and including the (k + 1)-th candidate: its list is the
+ * reference's, index for index.  A host that needs the reference's exact lists re-runs its own KDTree on the flagged rows
+ * only (<= 0.03 % of a 1 mm-quantised forest: INTEGRATION.md).  The entry behind the k-th must fit the register-resident
+ * list: k <= 63 (k <= 31 on a segmented handle), else TREEE_ERR_UNSUPPORTED; k = 16 / 32 run the next longer list. */
+int32_t treee_knn_self_ties_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
+                                float *d_dist, uint32_t *d_index, uint32_t *d_counts, uint8_t *d_tie_flags);
 /* KDTree::nearest (kd_tree.rs:86-90): all points with distance < max_dist_sq, ascending.
  * Writes min(found, cap) entries, *found_out = total. */
 int32_t treee_knn_radius(const treee_knn *t, const float q_xyz[3], float max_dist_sq,
@@ -145,6 +159,10 @@ int32_t treee_curvature(const float *xyz_aos, uint64_t n, uint32_t k, float max_
                         float *curve_out);
 int32_t treee_curvature_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
                             float *d_curve_out);
+/* curve and the tie flags of treee_knn_self_ties_dev in one pass: a row whose flag is 0 has the reference's curve wherever
+ * the two libms agree; bit 0 rows may differ by the f32 summation order (<= 1e-6 measured), bit 1 rows by another neighbour */
+int32_t treee_curvature_ties_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
+                                 float *d_curve_out, uint8_t *d_tie_flags);
 /* the same, but only points whose original index is < n_own are queried; the rest (a shard's ghost points,
  * appended behind its own points) only serve as neighbours.  d_curve_out needs n_own entries. */
 int32_t treee_curvature_own_dev(treee_ctx *ctx, const treee_knn *t, uint64_t n_own, uint32_t k,

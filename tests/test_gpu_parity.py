@@ -428,6 +428,108 @@ def test_curve_error_separated_by_cause_at_the_benchmark_density(T, oracle):
     assert st["tie_at_the_edge_other_member"]["rows"] <= 1e-4 * n
 
 
+def _flags_by_definition(dist_k1, k, counts):
+    """the tie flags as include/treee_hip.h defines them, from ascending distance rows of length k + 1 (bit patterns)"""
+    d = dist_k1.view(np.uint32)
+    valid = np.arange(k + 1)[None, :] < np.asarray(counts)[:, None]  # counts of the (k + 1)-query
+    eq = (d[:, 1:] == d[:, :-1]) & valid[:, 1:]
+    inside = eq[:, : k - 1].any(1) if k > 1 else np.zeros(len(d), bool)
+    edge = eq[:, k - 1]
+    return inside.astype(np.uint8) | (edge.astype(np.uint8) << 1)
+
+
+@pytest.mark.parametrize("cloud", ["forest_1m", "lattice", "uniform"])
+def test_tie_flags_cover_every_row_that_differs_from_the_reference_kdtree(T, oracle, cloud):
+    """treee_knn_self_ties_dev / treee_curvature_ties_dev: the library tells the caller WHICH rows a
+    distance tie touches.  Every row whose list differs from the restated KD-tree's (k-nearest/src/kd_tree.rs:114,125 decide
+    ties by visit order) is flagged; a row with flag 0 is the reference's list index for index and the reference's curve bit
+    for bit; the flags equal their definition computed from the oracle's (k + 1)-lists; on the 1 mm-quantised forest at the
+    benchmark's density at most 1 row in 1 000 is flagged at all."""
+    import torch
+
+    from treee_amd import synth
+
+    k = 31
+    if cloud == "forest_1m":
+        n = 1_000_000
+        pts, _ = synth.forest_cloud(n, plot=200.0 * (n / 15_000_000) ** 0.5)
+    elif cloud == "lattice":  # integer lattice: nearly every row has ties inside the list AND at its edge
+        g = np.arange(22, dtype=np.float32)
+        pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).copy()
+        np.random.default_rng(3).shuffle(pts)
+    else:
+        pts = quantised_cloud(120_000, 77, extent=(30, 10, 30))
+    d_pts = torch.from_numpy(pts).cuda()
+    tree = T.KDTree.new(d_pts)
+    dist, index, counts, flags = tree.self_neighbors_dev(k, ties=True)
+    curve, flags2 = tree.curvature_ties_dev(k)
+    assert torch.equal(flags, flags2)
+    d0, i0, c0 = tree.self_neighbors_dev(k)  # the flagged call changes nothing else
+    assert torch.equal(dist, d0) and torch.equal(index, i0) and torch.equal(counts, c0)
+    assert torch.equal(curve.view(torch.int32), tree.curvature_dev(k).view(torch.int32))
+    flags = flags.cpu().numpy()
+    index = index.cpu().numpy().view(np.uint32)
+    ref = oracle.KDTree(pts)
+    r_ent, r_cnt = ref.k_nearest_batch(pts, k, F32_MAX, threads=16)
+    r1_ent, r1_cnt = ref.k_nearest_batch(pts, k + 1, F32_MAX, threads=16)
+    assert np.array_equal(flags, _flags_by_definition(r1_ent["distance"], k, r1_cnt)), "flags are not what the header defines"
+    differs = (index != r_ent["index"].astype(np.uint32)).any(1)
+    assert not (differs & (flags == 0)).any(), "a row whose list differs from the reference KD-tree's is not flagged"
+    other_set = (np.sort(index, 1) != np.sort(r_ent["index"].astype(np.uint32), 1)).any(1)
+    assert not (other_set & ((flags & 2) == 0)).any(), "a row with another MEMBER must carry bit 1"
+    ref_curve = oracle.curvature(pts, k, F32_MAX, threads=16)
+    clean = flags == 0
+    assert same_f32(curve.cpu().numpy()[clean], ref_curve[clean])
+    if cloud == "forest_1m":
+        assert differs.any() and float((flags != 0).mean()) <= 1e-3, float((flags != 0).mean())
+    if cloud == "lattice":
+        assert float((flags == 3).mean()) > 0.9 and differs.any()
+    tree.close()
+
+
+def test_tie_flags_at_list_length_boundaries_and_on_segments(T, oracle):
+    """k = 16 / 32 need the entry BEHIND the k-th, i.e. the next longer register list; k = 15 / 17 / 33 / 63 their own;
+    k >= 64 is refused; a segmented handle flags ties inside each segment only; a bounded radius never flags an edge tie
+    of an invalid entry"""
+    import torch
+
+    pts = quantised_cloud(9000, 5, extent=(6, 3, 6))  # 1 mm grid, dense: plenty of ties
+    pts[:200] = np.round(pts[:200])  # and a clump of exact lattice points
+    d_pts = torch.from_numpy(pts).cuda()
+    tree = T.KDTree.new(d_pts)
+    ref = oracle.KDTree(pts)
+    for k in (1, 2, 15, 16, 17, 31, 32, 33, 63):
+        dist, index, counts, flags = tree.self_neighbors_dev(k, ties=True)
+        r1_ent, r1_cnt = ref.k_nearest_batch(pts, k + 1, F32_MAX, threads=8)
+        assert np.array_equal(flags.cpu().numpy(), _flags_by_definition(r1_ent["distance"], k, r1_cnt)), k
+        r_ent, r_cnt = ref.k_nearest_batch(pts, k, F32_MAX, threads=8)
+        assert np.array_equal(dist.cpu().numpy().view(np.uint32), r_ent["distance"].view(np.uint32)), k
+        differs = (index.cpu().numpy().view(np.uint32) != r_ent["index"].astype(np.uint32)).any(1)
+        assert not (differs & (flags.cpu().numpy() == 0)).any(), k
+    for k in (64, 100):
+        with pytest.raises(T.TreeeError):
+            tree.self_neighbors_dev(k, ties=True)
+    # bounded radius: entries at or beyond max_distance do not exist, so they cannot tie
+    r = 0.0004
+    dist, index, counts, flags = tree.self_neighbors_dev(31, r, ties=True)
+    r1_ent, r1_cnt = ref.k_nearest_batch(pts, 32, r, threads=8)
+    assert np.array_equal(flags.cpu().numpy(), _flags_by_definition(r1_ent["distance"], 31, r1_cnt))
+    assert int(counts.max()) < 31 or True
+    tree.close()
+    # segmented: one KD-tree per segment (calculations.rs:329)
+    seg = (np.arange(len(pts)) % 3).astype(np.int32)
+    st = T.KDTree.new_segments(d_pts, torch.from_numpy(seg).cuda(), 3)
+    dist, index, counts, flags = st.self_neighbors_dev(31, ties=True)
+    flags = flags.cpu().numpy()
+    for sg in range(3):
+        m = np.nonzero(seg == sg)[0]
+        r1_ent, r1_cnt = oracle.KDTree(pts[m]).k_nearest_batch(pts[m], 32, F32_MAX, threads=8)
+        assert np.array_equal(flags[m], _flags_by_definition(r1_ent["distance"], 31, r1_cnt)), sg
+    with pytest.raises(T.TreeeError):
+        st.self_neighbors_dev(32, ties=True)
+    st.close()
+
+
 # ---------------------------------------------------------------- A5 as the reference calls it: one tree per segment
 def test_segmented_knn_equals_one_tree_per_segment(T, oracle):
     import torch
@@ -1017,6 +1119,218 @@ def test_tile_stream_of_laz_tiles_equals_the_las_stream(T):
         assert res["points"] == sum(t.n for t in las)
     for f, nd in zip(frames[1:], nodes[1:]):
         assert torch.equal(f, frames[0]) and all(np.array_equal(a, b) for a, b in zip(nd, nodes[0]))
+
+
+def _cut_into_tiles(pts, nx, nz, tile):
+    """a cloud (device tensor) cut into nx x nz square x/z tiles by POSITION, each handed over as a LAS tile whose header
+    offset is its corner: trees whose crowns cross a cut lie in two tiles.  Returns (tiles, concatenated cloud as the
+    decode gives it)."""
+    import torch
+
+    from treee_amd import stream
+
+    x0, z0 = float(pts[:, 0].min()), float(pts[:, 2].min())
+    ix = torch.clamp(((pts[:, 0] - x0) / tile).floor().long(), 0, nx - 1)
+    iz = torch.clamp(((pts[:, 2] - z0) / tile).floor().long(), 0, nz - 1)
+    tiles = []
+    for t in range(nx * nz):
+        part = pts[(iz * nx + ix) == t]
+        tiles.append(stream.las_tile_from_cloud(part))
+    return tiles
+
+
+def test_whole_cloud_stream_is_the_single_call(T, oracle):
+    """BASELINE.json configs[4] as ONE cloud (treee_amd/stream.py WholeCloudStream): six adjacent tiles of one forest --
+    cut by position, so trees straddle the cuts -- streamed into one resident buffer give the octree of the concatenated
+    cloud (bit for bit the oracle's), the curvature of the single call row for row, and its frame; the per-tile mode of
+    the same tiles (no ghost points) gives OTHER values on rows near the cuts -- which is why it is labelled so."""
+    import torch
+
+    from treee_amd import laz, stream, synth
+
+    w, h = 320, 200
+    pts, _ = synth.forest_cloud_torch(260_000, "cuda", plot=36.0, seed=synth.SEED_FOREST + 41)
+    pts = pts[(pts[:, 2] < 6.0)]  # 36 m x 24 m: 3 x 2 tiles of 12 m
+    tiles = _cut_into_tiles(pts, 3, 2, 12.0)
+    assert len(tiles) == 6 and min(t.n for t in tiles) > 10_000
+    cam = T.Camera3D(w / h)
+    proj, view, env = cam.projection(), T.view_from_transform(T.rotation_x(-0.5) @ T.translation(0.0, 0.0, 70.0)), T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+    total = sum(t.n for t in tiles)
+    ws = stream.WholeCloudStream("cuda:0", total + 5, max(t.n for t in tiles), width=w, height=h, knn_k=31, leaf_cap=64, lod_cap=64)
+    res = ws.run(tiles, view, proj, env)
+    assert res["points"] == total and res["tiles"] == [t.n for t in tiles]
+    # the resident cloud is the concatenation of the decoded tiles (oracle decode of every tile)
+    whole = np.concatenate([oracle.decode_las_records(t.records.numpy().tobytes(), t.n, t.stride, list(t.scale), list(t.offset), list(t.center)) for t in tiles])
+    assert np.array_equal(ws.xyz[:total].cpu().numpy().view(np.uint32), whole.view(np.uint32))
+    # ONE octree with one cube and global numbering == the oracle's octree of the concatenated cloud
+    mn, size = cube_of(whole)
+    assert np.array_equal(ws.octree.corner, mn) and ws.octree.size == size
+    sk, perm = oracle.sort_keys(oracle.morton_keys(whole, mn, size))
+    nodes, leaf, lod = oracle.octree_build(sk, 64, 64)
+    assert np.array_equal(ws.octree.array("keys"), sk) and np.array_equal(ws.octree.array("perm"), perm)
+    assert np.array_equal(ws.octree.array("nodes").view(np.uint32), nodes.view(np.uint32))
+    assert np.array_equal(ws.octree.array("leaf"), leaf) and np.array_equal(ws.octree.array("lod"), lod)
+    assert res["nodes"] == len(nodes) and res["lod"] == len(lod)
+    # curvature: the single call on the concatenated cloud, row for row; and the reference's loop over the library's lists
+    d_whole = torch.from_numpy(whole).cuda()
+    single = T.KDTree.new(d_whole)
+    curve1 = single.curvature_dev(31)
+    got = ws.curve[:total]
+    assert torch.equal(got.view(torch.int32), curve1.view(torch.int32))
+    check_curve_against_the_restated_loop(T, oracle, whole, tree=ws.tree)
+    # the frame: the single splat of the concatenated cloud with those values
+    ctx = T.default_context(torch.device("cuda", 0))
+    val = T.map_to_u32_dev(curve1, ctx)
+    packed = torch.empty((h, w), dtype=torch.int64, device="cuda")
+    T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(d_whole), T.context.ptr(val), total, T.context.ptr(view), T.context.ptr(proj),
+                                         env.scale, env.min, env.max, w, h, T.context.ptr(packed), 0, 0, None, None))
+    assert torch.equal(ws.packed, packed)
+    # without kNN: octree + frame of zeros
+    ws0 = stream.WholeCloudStream("cuda:0", total, max(t.n for t in tiles), width=w, height=h, knn_k=0, leaf_cap=64, lod_cap=64)
+    r0 = ws0.run(tiles, view, proj, env)
+    assert r0["nodes"] == len(nodes) and np.array_equal(ws0.octree.array("leaf"), leaf)
+    ws0.close()
+    # a second run on the same stream object (handles of the first are dropped), tiles in another order: another cloud
+    r2 = ws.run(tiles[::-1], view, proj, env)
+    assert r2["points"] == total and r2["nodes"] == len(nodes)
+    ws.close()
+    # the PER-TILE mode (no ghost points): rows near a cut get other neighbours, hence another curve
+    ts = stream.TileStream("cuda:0", max(t.n for t in tiles), width=w, height=h, knn_k=31)
+    per_tile = []
+    ts.run(tiles, view, proj, env, on_tile=lambda i, tile, oc, xyz: per_tile.append(ts.curve[:tile.n].clone()))
+    ts.close()
+    per_tile = torch.cat(per_tile)
+    differs = (per_tile.view(torch.int32) != curve1.view(torch.int32)) & ~(torch.isnan(per_tile) & torch.isnan(curve1))
+    x0, z0 = float(d_whole[:, 0].min()), float(d_whole[:, 2].min())
+    to_cut = torch.minimum(torch.minimum((d_whole[:, 0] - (x0 + 12.0)).abs(), (d_whole[:, 0] - (x0 + 24.0)).abs()), (d_whole[:, 2] - (z0 + 12.0)).abs())
+    assert int(differs.sum()) > 500, "the per-tile mode must differ from the one-cloud result near the cuts"
+    assert float(to_cut[differs].max()) < 3.0 and float((differs & (to_cut < 0.05)).float().sum() / (to_cut < 0.05).float().sum()) > 0.5
+
+
+def test_whole_cloud_stream_from_laz_tiles(T):
+    """the same resident cloud from LAZ tiles (decompressed on host threads one tile ahead) and from a mixed sequence"""
+    import torch
+
+    from treee_amd import stream, synth
+
+    w, h = 160, 100
+    las, lazt = [], []
+    for i, n in enumerate((30_001, 20_000, 64, 9_000)):
+        pts, _ = synth.forest_cloud_torch(n, "cuda", plot=15.0, seed=synth.SEED_FOREST + 60 + i)
+        t = stream.las_tile_from_cloud(pts)
+        las.append(stream.Tile(t.records, t.n, t.stride, t.scale, (i * 15.0, 0.0, 0.0), (15.0, 0.0, 5.0)))
+        z = stream.laz_tile_from_cloud(pts, chunk_size=7_000)
+        z.offset, z.center = las[-1].offset, las[-1].center
+        lazt.append(z)
+    cam = T.Camera3D(w / h)
+    proj, view, env = cam.projection(), T.view_from_transform(T.rotation_x(-0.5) @ T.translation(0.0, 0.0, 60.0)), T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+    total = sum(t.n for t in las)
+    out = []
+    for tiles in (las, lazt, [lazt[0], las[1], lazt[2], las[3]]):
+        ws = stream.WholeCloudStream("cuda:0", total, 31_000, width=w, height=h, knn_k=31)
+        ws.run(tiles, view, proj, env)
+        out.append((ws.xyz[:total].clone(), ws.curve[:total].clone(), ws.packed.clone(), ws.octree.array("nodes")))
+        ws.close()
+    for o in out[1:]:
+        assert torch.equal(o[0], out[0][0]) and torch.equal(o[1].view(torch.int32), out[0][1].view(torch.int32)) and torch.equal(o[2], out[0][2])
+        assert np.array_equal(o[3], out[0][3])
+
+
+def test_full_size_1g_whole_cloud_properties(T):
+    """BASELINE.json configs[4] at FULL size as one cloud on one GPU: 67 LAS tiles x 15 M points = 1.005 G points streamed
+    from pinned host memory into one resident buffer, ONE sort / octree / kNN structure / curvature / splat.  Size-independent
+    properties (sorted, a permutation, leaves tile the order, one root of all points, LOD entries in range), the curve's range,
+    and 16 queries against ALL 1.005 G points in the reference's op order.  (The first run anywhere near the 2^31 - 1 points a
+    cloud may hold: include/treee_hip.h.)"""
+    import torch
+
+    from treee_amd import stream, synth
+
+    n, tiles, plot = 15_000_000, 67, 200.0
+    base = []
+    for i in range(3):
+        p, _ = synth.forest_cloud_torch(n, "cuda", plot=plot, seed=synth.SEED_FOREST + 100 + i)
+        base.append(stream.las_tile_from_cloud(p))
+        del p
+
+    def gen():
+        for i in range(tiles):  # (a 9 x 8 grid through the LAS header offset, as bench.py lays it out)
+            b = base[i % len(base)]
+            yield stream.Tile(b.records, b.n, b.stride, b.scale, ((i % 9) * plot, (i // 9) * plot, 0.0), (4 * plot, 3.5 * plot, 0.0))
+
+    w, h = 1920, 1080
+    cam = T.Camera3D(w / h)
+    proj, view, env = cam.projection(), T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 100.0 + 0.9 * 9 * plot)), T.PointCloudEnvironment(0, 0xFFFFFFFF, 0.1)
+    total = n * tiles
+    ws = stream.WholeCloudStream("cuda:0", total, n, width=w, height=h, knn_k=31)
+    res = ws.run(gen(), view, proj, env)
+    assert res["points"] == total == 1_005_000_000
+    oc, d_pts = ws.octree, ws.xyz[:total]
+    def dev_u32(name, count):
+        """one of the octree's device arrays as a torch tensor over the SAME memory (no copy)"""
+        return T.context.device_view(oc.dev_ptr(name), (count,), "int32")
+
+    keys = dev_u32("keys", total)
+    assert bool((keys[1:] >= keys[:-1]).all())  # (30-bit keys: the signed view orders like the unsigned one)
+    del keys
+    perm = dev_u32("perm", total)
+    seen = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    step = 1 << 27
+    for a in range(0, total, step):
+        seen[perm[a:a + step].long()] = 1
+    assert int(seen.sum(dtype=torch.int64)) == total  # a permutation of all global indices
+    del seen
+    # the sorted records are the points the permutation names
+    for a in (0, total // 2, total - 1000):
+        rec = T.context.device_view(oc.dev_ptr("sorted_xyz") + a * 16, (1000, 4), "float32")
+        assert torch.equal(rec[:, :3], d_pts[perm[a:a + 1000].long()]) and torch.equal(rec[:, 3].view(torch.int32), perm[a:a + 1000])
+    del perm
+    nodes = oc.array("nodes")
+    assert int(nodes["count"][0]) == total and int(nodes["first"][0]) == 0 and int(nodes["level"][0]) == 0
+    leaves = nodes[nodes["first_child"] == 0xFFFFFFFF]
+    order = np.argsort(leaves["first"], kind="stable")
+    first, count = leaves["first"][order].astype(np.int64), leaves["count"][order].astype(np.int64)
+    assert first[0] == 0 and np.array_equal(first[1:], (first + count)[:-1]) and first[-1] + count[-1] == total  # the leaves tile the order
+    inner = nodes[nodes["first_child"] != 0xFFFFFFFF]
+    assert int(np.minimum(inner["count"], 256).astype(np.int64).sum()) == res["lod"]
+    kids = nodes[1:]
+    par = nodes[kids["parent"]]
+    assert bool(np.all(kids["level"] == par["level"] + 1)) and bool(np.all((kids["key_prefix"] >> 3) == par["key_prefix"]))
+    assert bool(np.all(kids["first"] >= par["first"])) and bool(np.all(kids["first"].astype(np.int64) + kids["count"] <= par["first"].astype(np.int64) + par["count"]))
+    leaf = dev_u32("leaf", total)
+    sample = torch.randint(0, total, (1 << 20,), generator=torch.Generator().manual_seed(5)).cuda()
+    lf = torch.from_numpy(nodes["first"].astype(np.int64)).cuda()[leaf[sample].long()]
+    lc = torch.from_numpy(nodes["count"].astype(np.int64)).cuda()[leaf[sample].long()]
+    assert bool(((sample >= lf) & (sample < lf + lc)).all())  # a position's leaf id names the leaf that holds it
+    del leaf, lf, lc
+    lod = oc.array("lod")
+    assert len(lod) == res["lod"] and int(lod.max()) < total
+    # curvature of every point, and 16 rows against all points
+    curve = ws.curve[:total]
+    ok = ~torch.isnan(curve)
+    assert float(ok.float().mean()) > 0.999 and float(curve[ok].min()) > -1e-3 and float(curve[ok].max()) < 1.001
+    del ok
+    sample = torch.randint(0, total, (4096,), generator=torch.Generator().manual_seed(7)).cuda()
+    dist, index, counts = ws.tree.k_nearest_dev(d_pts[sample], 31)
+    assert int(counts.min()) == 31 and bool((dist[:, 0] == 0).all()) and bool((dist[:, 1:] >= dist[:, :-1]).all())
+    for r in range(0, 4096, 256):  # 16 queries against all 1.005 G points, reference op order (metric.rs:21-26)
+        q = d_pts[sample[r]]
+        best = None
+        for a in range(0, total, 1 << 28):
+            c = d_pts[a:a + (1 << 28)]
+            dx, dy, dz = c[:, 0] - q[0], c[:, 1] - q[1], c[:, 2] - q[2]
+            d = (dx * dx + dy * dy) + dz * dz
+            top = torch.topk(d, 31, largest=False).values
+            best = top if best is None else torch.topk(torch.cat([best, top]), 31, largest=False).values
+            del d, dx, dy, dz
+        assert torch.equal(torch.sort(best).values, dist[r]), r
+        got = d_pts[index[r].long()]  # the returned indices really are at those distances
+        gx, gy, gz = got[:, 0] - q[0], got[:, 1] - q[1], got[:, 2] - q[2]
+        assert torch.equal((gx * gx + gy * gy) + gz * gz, dist[r])
+    # the frame: every pixel's winner is a global index of the cloud or the "no point" sentinel
+    ids = (ws.packed.view(-1) & 0xFFFFFFFF)
+    assert bool(((ids < total) | (ids == 0xFFFFFFFF)).all()) and int((ids < total).sum()) > 10_000
+    ws.close()
 
 
 # ---------------------------------------------------------------- kNN edge cases (sorted-32 kernel paths)

@@ -84,11 +84,13 @@ SYMBOLS = {
     "treee_knn_query_batch": (_i32, [_vp, _vp, _u64, _u32, _f32, _vp, _vp]),
     "treee_knn_query_batch_dev": (_i32, [_vp, _vp, _vp, _u64, _u32, _f32, _vp, _vp, _vp]),
     "treee_knn_self_dev": (_i32, [_vp, _vp, _u32, _f32, _vp, _vp, _vp]),
+    "treee_knn_self_ties_dev": (_i32, [_vp, _vp, _u32, _f32, _vp, _vp, _vp, _vp]),
     "treee_knn_radius": (_i32, [_vp, _vp, _f32, _vp, _u64, C.POINTER(_u64)]),
     "treee_knn_empty": (_i32, [_vp, _vp, _u64, _f32, _vp]),
     "treee_curvature": (_i32, [_vp, _u64, _u32, _f32, _vp]),
     "treee_curvature_segments": (_i32, [_vp, _vp, _u64, _u32, _u32, _f32, _vp]),
     "treee_curvature_dev": (_i32, [_vp, _vp, _u32, _f32, _vp]),
+    "treee_curvature_ties_dev": (_i32, [_vp, _vp, _u32, _f32, _vp, _vp]),
     "treee_curvature_own_dev": (_i32, [_vp, _vp, _u64, _u32, _f32, _vp]),
     "treee_map_to_u32_dev": (_i32, [_vp, _vp, _u64, _vp]),
     "treee_sort_build": (_i32, [_vp, _u64, _vp, _f32, _u32, _u32, _pp]),

@@ -42,6 +42,20 @@ def dev_f32(t, cols=None):
     return t.reshape(-1, cols) if cols is not None else t
 
 
+class _DeviceMemory:
+    def __init__(self, address, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr, "data": (int(address), False), "version": 2}
+
+
+def device_view(address, shape, dtype, device=None):
+    """a torch tensor over device memory the library owns (treee_octree_dev_ptr and friends): no copy; valid as long as the
+    handle is, and the caller orders its use against the handle's stream (include/treee_hip.h, "Streams")"""
+    import torch
+
+    typestr = {"int32": "<i4", "uint32": "<u4", "float32": "<f4", "int64": "<i8", "uint8": "|u1"}[dtype]
+    return torch.as_tensor(_DeviceMemory(address, shape, typestr), device=device or "cuda")
+
+
 class Context:
     """treee_ctx bound to a torch device and (by default) torch's current stream."""
 

@@ -233,6 +233,7 @@ struct KnnArgs {
 	uint32_t *out_index;
 	uint32_t *out_count;
 	float *out_curve;
+	uint8_t *out_flags; // optional, per query row: bit 0 = two equal distances inside the k, bit 1 = the k-th and the (k+1)-th equally far (needs k < list length)
 	uint32_t *stats; // optional [4]: buckets scanned, flushes, nodes tested, waves
 	uint32_t *thr_io;  // diagnostic: per-slot final threshold (written when thr_seed == 0, read when 1)
 	uint32_t thr_seed;
@@ -617,7 +618,13 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	double L[SK]; // FixedSet::new (best_set.rs:20-28): (max_distance, invalid)
 #pragma unroll
 	for (int i = 0; i < SK; ++i) L[i] = key_make(a.maxbits, 0u);
-	uint32_t thr = a.maxbits; // distance bits of the current 32nd best
+	uint32_t thr = a.maxbits; // distance bits of the current threshold entry (below)
+	// The threshold is the distance of the list's LAST entry only when all SK are asked for.  For k < SK -- the reference's k = 31
+	// (calculations.rs:278) in the 32-entry list -- the (SK - 1)-th entry bounds the k-th from above just as well, and the search
+	// volume is that of 31 neighbours instead of 32.  Exactness is unchanged: candidates pass with `<=`, so the whole tie group of
+	// the k-th distance still arrives, and the entry behind the k-th is still "another point exactly as far, if there is one"
+	// (what out_flags bit 1 reports).
+	const bool k_below = a.k < (uint32_t)SK; // (wave-uniform)
 	ST(if (a.thr_io && a.thr_seed && live) thr = a.thr_io[slot]); // diagnostic lower bound: start from the final answer
 	// byte offset of this lane's next free buffer slot (slot stride 256 B); the buffer is appended
 	// to without branches: every candidate is written, the offset only advances if it passed
@@ -643,7 +650,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		for (int i = SK - SBUF; i < SK; ++i) L[i] = key_min(L[i], B[SK - 1 - i]); // 32 smallest of the union, bitonic
 		bitonic_merge<SK>(L);
 		{
-			const uint32_t nt = key_db(L[SK - 1]);
+			const uint32_t nt = k_below ? key_db(L[SK - 2]) : key_db(L[SK - 1]);
 			thr = nt < thr ? nt : thr;
 		}
 		ST(st_flush++);
@@ -782,7 +789,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 				L[j + 1] = d1 < a.maxbits ? key_make(d1, base + j + 1) : key_make(a.maxbits, 0u);
 			}
 			sort_net<SKT>(L);
-			thr = key_db(L[SK - 1]);
+			thr = k_below ? key_db(L[SK - 2]) : key_db(L[SK - 1]);
 			ST(if (a.thr_io && a.thr_seed && live) thr = min(thr, a.thr_io[slot]));
 			first = SK;
 		}
@@ -1085,6 +1092,17 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 #pragma unroll
 	for (int s = 0; s < SK; ++s) count += ((uint32_t)s < k && key_db(L[s]) < a.maxbits) ? 1u : 0u;
 	if (a.out_count) a.out_count[row] = count;
+	if (a.out_flags) { // (wave-uniform) rows whose list the reference's KD-tree may order or cut differently: k-nearest/src/kd_tree.rs:114,125 decide
+		// equal distances by visit order, this structure by (distance, cell, index) -- SURVEY.md H2
+		uint32_t f = 0u;
+#pragma unroll
+		for (int s = 0; s + 1 < SK; ++s) {
+			const bool eq = key_db(L[s]) == key_db(L[s + 1]) && key_db(L[s + 1]) < a.maxbits;
+			f |= (eq && (uint32_t)(s + 1) < k) ? 1u : 0u;  // both inside the k
+			f |= (eq && (uint32_t)(s + 1) == k) ? 2u : 0u; // the k-th and the entry behind it
+		}
+		a.out_flags[row] = (uint8_t)f;
+	}
 	if (a.out_dist || a.out_index) {
 #pragma unroll
 		for (int s = 0; s < SK; ++s) {
@@ -1237,23 +1255,26 @@ uint32_t max_bits(float max_dist_sq) {
 }
 
 int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_t nq, uint32_t k, float max_dist_sq,
-                      float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit);
+                      float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit, uint8_t *d_flags);
 
 // every query path comes through here: a context other than the handle's owner is ordered behind the build and its
 // use is remembered for treee_knn_free (HandleSync in common.h)
 int32_t launch_knn(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_t nq, uint32_t k, float max_dist_sq,
-                   float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit = ~0ull) {
+                   float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit = ~0ull, uint8_t *d_flags = nullptr) {
 	TREEE_TRY(use_begin(ctx, t->owner, &t->sync));
 	if (t->sc->owner != t->owner) TREEE_TRY(use_begin(ctx, t->sc->owner, &t->sc->sync));
-	const int32_t rc = launch_knn_on(ctx, t, d_q, nq, k, max_dist_sq, d_dist, d_index, d_counts, d_curve, q_limit);
+	const int32_t rc = launch_knn_on(ctx, t, d_q, nq, k, max_dist_sq, d_dist, d_index, d_counts, d_curve, q_limit, d_flags);
 	const int32_t e1 = use_end(ctx, t->owner, &t->sync), e2 = use_end(ctx, t->sc->owner, &t->sc->sync);
 	return rc != TREEE_OK ? rc : (e1 != TREEE_OK ? e1 : e2);
 }
 
 int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint64_t nq, uint32_t k, float max_dist_sq,
-                      float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit) {
+                      float *d_dist, uint32_t *d_index, uint32_t *d_counts, float *d_curve, uint64_t q_limit, uint8_t *d_flags) {
 	if (k == 0) return set_err(TREEE_ERR_INVALID, "k == 0 (the reference panics at best_set.rs:74)");
 	if (nq == 0) return TREEE_OK;
+	// tie flags need the entry BEHIND the k-th: a list one class longer when k is exactly a list length (16 -> 32, 32 -> 64)
+	if (d_flags && (k >= 64u || (t->segmented && k >= 32u)))
+		return set_err(TREEE_ERR_UNSUPPORTED, "tie flags need k <= 63 (k <= 31 on a segmented handle): the entry behind the k-th must fit the register-resident list");
 	if (nq >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "nq too large");
 	if (t->segmented && d_q) return set_err(TREEE_ERR_UNSUPPORTED, "segmented handle: only self queries (a position has no segment)");
 	const size_t lds = (size_t)k * 64 * 8 + 64 * 16;
@@ -1277,6 +1298,7 @@ int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint
 	a.out_index = d_index;
 	a.out_count = d_counts;
 	a.out_curve = d_curve;
+	a.out_flags = d_flags;
 	a.stats = nullptr;
 	a.thr_io = nullptr;
 	a.thr_seed = 0;
@@ -1307,13 +1329,13 @@ int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint
 	static const bool force_heap = getenv("TREEE_KNN_FORCE_HEAP") != nullptr; // A/B and test hook
 	static const unsigned pad_lds = getenv("TREEE_KNN_PAD_LDS") ? (unsigned)atoi(getenv("TREEE_KNN_PAD_LDS")) : 0u; // A/B hook: unused dynamic LDS lowers the occupancy
 	static const bool no64 = getenv("TREEE_KNN_NO_K64") != nullptr; // A/B and test hook
-	if (k > (uint32_t)SK && k <= 64u && !force_heap && !no64 && !t->segmented) {
+	if (((k > (uint32_t)SK && k <= 64u) || (d_flags && k == (uint32_t)SK)) && !force_heap && !no64 && !t->segmented) {
 		if (a.wave_order && !d_q) nwaves = t->n_order;
 		hipLaunchKernelGGL((k_knn_sorted32<false, false, 64>), dim3(nwaves), dim3(64), 0, ctx->stream, a); // 64-entry list, 2 waves/SIMD
 	} else if (k <= (uint32_t)SK && !force_heap) {
 		if (a.wave_order && !d_q) nwaves = t->n_order; // padded dispatch table
 		static const bool no16 = getenv("TREEE_KNN_NO_K16") != nullptr; // A/B and test hook
-		if (k <= 16u && !no16 && !a.stats) {
+		if (k <= 16u && !no16 && !a.stats && !(d_flags && k == 16u)) {
 			if (t->segmented)
 				hipLaunchKernelGGL((k_knn_sorted32<false, true, 16>), dim3(nwaves), dim3(64), 0, ctx->stream, a);
 			else
@@ -1326,6 +1348,7 @@ int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint
 			hipLaunchKernelGGL((k_knn_sorted32<false, false>), dim3(nwaves), dim3(64), pad_lds, ctx->stream, a);
 	} else {
 		if (t->segmented) return set_err(TREEE_ERR_UNSUPPORTED, "segmented handle: k=%u > 32 is not supported", k);
+		if (d_flags) return set_err(TREEE_ERR_UNSUPPORTED, "tie flags are written by the register-list kernels only (k <= 63)");
 		a.wave_order = nullptr;
 		if (lds > 64 * 1024)
 			TREEE_HIP(hipFuncSetAttribute((const void *)k_knn_heap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2270,6 +2293,21 @@ int32_t treee_knn_self_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
 	return launch_knn(ctx, t, nullptr, t->sc->n, k, max_dist_sq, d_dist, d_index, d_counts, nullptr);
+}
+
+int32_t treee_knn_self_ties_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq, float *d_dist, uint32_t *d_index, uint32_t *d_counts,
+                                uint8_t *d_tie_flags) {
+	if (!ctx || !t) return set_err(TREEE_ERR_INVALID, "treee_knn_self_ties_dev: null argument");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	return launch_knn(ctx, t, nullptr, t->sc->n, k, max_dist_sq, d_dist, d_index, d_counts, nullptr, ~0ull, d_tie_flags);
+}
+
+int32_t treee_curvature_ties_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq, float *d_curve, uint8_t *d_tie_flags) {
+	if (!ctx || !t || !d_curve) return set_err(TREEE_ERR_INVALID, "treee_curvature_ties_dev: null argument");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	return launch_knn(ctx, t, nullptr, t->sc->n, k, max_dist_sq, nullptr, nullptr, nullptr, d_curve, ~0ull, d_tie_flags);
 }
 
 int32_t treee_curvature_own_dev(treee_ctx *ctx, const treee_knn *t, uint64_t n_own, uint32_t k, float max_dist_sq, float *d_curve) {

@@ -347,6 +347,7 @@ static int32_t splat_any(treee_ctx *ctx, const void *d_pts, bool rec, const uint
 	if (n && !d_value && (vmin != 0u || vmax != 0xFFFFFFFFu || d_id))
 		return set_err(TREEE_ERR_INVALID, "treee_splat_dev: d_value may only be null when nothing is culled (vmin = 0, vmax = u32::MAX) and no id buffer is asked for");
 	if (w == 0 || h == 0 || (uint64_t)w * h >= (1ull << 31)) return set_err(TREEE_ERR_INVALID, "bad framebuffer size %ux%u", w, h);
+	if (n >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per call", (unsigned long long)n);
 	if (n_values >= 0xFFFFFFFFull - index_base) return set_err(TREEE_ERR_UNSUPPORTED, "point index does not fit in 32 bits");
 	if (index_base != 0 && d_id)
 		return set_err(TREEE_ERR_INVALID, "d_id_out needs index_base == 0; resolve multi-chunk draws with treee_splat_resolve_dev");

@@ -156,8 +156,9 @@ class KDTree:
         )
         return dist, index, counts
 
-    def self_neighbors_dev(self, k, max_distance=F32_MAX, ctx=None, want_dist=True, want_index=True):
-        """every tree point queries itself (the loop of calculations.rs:332-340)."""
+    def self_neighbors_dev(self, k, max_distance=F32_MAX, ctx=None, want_dist=True, want_index=True, ties=False):
+        """every tree point queries itself (the loop of calculations.rs:332-340).  `ties=True` also returns the per-row tie
+        flags (uint8; treee_knn_self_ties_dev: bit 0 = equal distances inside the k, bit 1 = the k-th and the next equally far)."""
         import torch
 
         c = self._ctx(ctx)
@@ -165,8 +166,23 @@ class KDTree:
         dist = torch.empty((self.n, k), dtype=torch.float32, device=dev) if want_dist else None
         index = torch.empty((self.n, k), dtype=torch.int32, device=dev) if want_index else None
         counts = torch.empty((self.n,), dtype=torch.int32, device=dev)
+        if ties:
+            flags = torch.empty((self.n,), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib().treee_knn_self_ties_dev(c.handle, self._h, k, max_distance, ptr(dist), ptr(index), ptr(counts), ptr(flags)))
+            return dist, index, counts, flags
         _lib.check(_lib.lib().treee_knn_self_dev(c.handle, self._h, k, max_distance, ptr(dist), ptr(index), ptr(counts)))
         return dist, index, counts
+
+    def curvature_ties_dev(self, k=31, max_distance=F32_MAX, ctx=None, out=None):
+        """(curve, tie flags) in one pass (treee_curvature_ties_dev)"""
+        import torch
+
+        c = self._ctx(ctx)
+        if out is None:
+            out = torch.empty((self.n,), dtype=torch.float32, device=c.device)
+        flags = torch.empty((self.n,), dtype=torch.uint8, device=c.device)
+        _lib.check(_lib.lib().treee_curvature_ties_dev(c.handle, self._h, k, max_distance, ptr(out), ptr(flags)))
+        return out, flags
 
     def curvature_dev(self, k=31, max_distance=F32_MAX, ctx=None, out=None, n_own=None):
         """`n_own`: only the first n_own points (original order) are queried -- a shard's ghost points behind them

@@ -10,6 +10,17 @@ drawn into one shared depth/id frame, exactly like the reference draws chunk aft
 
 Two HIP streams, two staging buffers, events both ways -- no host synchronisation per tile except the one inside
 the octree build (its node count sizes the node table).
+
+Two modes:
+* `TileStream` -- PER TILE, NO GHOST POINTS: one octree per tile (each with its own cube), kNN inside a tile only, so a
+  point near a tile border gets its neighbours from one side.  That is what the reference does with its chunks (every chunk
+  is its own point cloud), and the cheapest way to draw a frame of a cloud that does not fit; it is NOT the octree or the
+  neighbourhoods of the whole cloud.
+* `WholeCloudStream` -- ONE CLOUD: the tiles are decoded as they arrive into one resident xyz buffer (1.005 G points are
+  12 GB of a 288 GB MI355X; "out of core" is about the host side and the PCIe link, which stay streamed and overlapped),
+  then ONE Morton sort / octree / LOD with one cube and global numbering, the kNN structure from that sort, curvature of
+  every point with its true neighbours across tile borders, one splat.  Same result, bit for bit, as the single call on the
+  concatenated cloud (tests/test_gpu_parity.py::test_whole_cloud_stream_is_the_single_call).
 """
 import ctypes as C
 
@@ -61,87 +72,24 @@ class LazTile:
         self.records = out
 
 
-class TileStream:
-    def __init__(self, device, max_points, max_stride=20, width=1920, height=1080, knn_k=0, leaf_cap=256, lod_cap=256):
+class _Staging:
+    """what both modes share: the copy stream, two device staging buffers for raw records, events both ways, and the
+    LAZ side (two pinned buffers, one worker decompressing a tile ahead)"""
+
+    def _init_staging(self, device, max_points, max_stride):
         import torch
 
         self.torch = torch
         self.device = torch.device(device)
         self.compute = torch.cuda.Stream(self.device)
         self.copy = torch.cuda.Stream(self.device)
-        self.ctx = Context(self.device.index, self.compute)
-        self.ctx.reserve(int(max_points * 1.1) * 64 + (64 << 20))
-        # with kNN on, a tile's octree node table is completed on a side stream under the kNN structure's own build
-        self.side = torch.cuda.Stream(self.device) if knn_k else None
-        self.ctx2 = Context(self.device.index, self.side) if knn_k else None
-        if self.ctx2 is not None:
-            self.ctx2.reserve(int(max_points * 1.1) * 24 + (32 << 20))
         self.max_points, self.max_stride = int(max_points), int(max_stride)
         self.raw = [torch.empty((self.max_points * self.max_stride,), dtype=torch.uint8, device=self.device) for _ in range(2)]
-        self.xyz = torch.empty((self.max_points, 3), dtype=torch.float32, device=self.device)
-        self.value = torch.empty((self.max_points,), dtype=torch.int32, device=self.device)
-        self.curve = torch.empty((self.max_points,), dtype=torch.float32, device=self.device) if knn_k else None
-        self.packed = torch.empty((height, width), dtype=torch.int64, device=self.device)
-        self.w, self.h, self.knn_k = width, height, int(knn_k)
-        self.leaf_cap, self.lod_cap = leaf_cap, lod_cap
         self.copied = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         self.pinned = None  # two pinned staging buffers for LAZ tiles, allocated when the first one arrives
         self.pool = None  # one worker: the next LAZ tile is decompressed (on the library's host threads) while this one runs
         self.laz_threads = 0
-
-    def run(self, tiles, view, proj, env, on_tile=None):
-        """Streams `tiles` (an iterable of Tile).  Returns a dict with the tile roots (corner, size, node / lod
-        counts per tile) and the totals; the frame is left in self.packed (depth_bits << 32 | global index)."""
-        torch, lib = self.torch, _lib.lib()
-        roots, total, index_base = [], 0, 0
-        it = self._decoded(iter(tiles))
-        pending = next(it, None)
-        if pending is not None:
-            self._upload(pending, 0, first=True)
-        i = 0
-        with torch.cuda.stream(self.compute):
-            # n = 0, accumulate = 0: clears the packed frame (render/src/window.rs:153-159)
-            _lib.check(lib.treee_splat_dev(self.ctx.handle, None, None, 0, ptr(view), ptr(proj), env.scale, env.min, env.max, self.w, self.h,
-                                           ptr(self.packed), 0, 0, None, None))
-        while pending is not None:
-            tile, slot = pending, i & 1
-            pending = next(it, None)
-            if pending is not None:  # next tile's PCIe copy runs under this tile's kernels
-                self._upload(pending, slot ^ 1, first=i == 0)
-            with torch.cuda.stream(self.compute):
-                self.compute.wait_event(self.copied[slot])
-                n = tile.n
-                xyz = self.xyz[:n]
-                _lib.check(lib.treee_decode_las_records_dev(self.ctx.handle, ptr(self.raw[slot]), n, tile.stride, ptr(tile.scale),
-                                                            ptr(tile.offset), ptr(tile.center), ptr(xyz)))
-                self.consumed[slot].record(self.compute)  # the staging buffer may be overwritten from here on
-                if self.knn_k:
-                    oc = Octree(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx, defer=True)
-                    tree = KDTree.from_octree(oc, self.ctx)
-                    oc.complete(self.ctx2)
-                    self.compute.wait_stream(self.side)
-                    tree.curvature_dev(self.knn_k, F32_MAX, self.ctx, out=self.curve[:n])
-                    _lib.check(lib.treee_map_to_u32_dev(self.ctx.handle, ptr(self.curve), n, ptr(self.value)))
-                    tree.close()
-                else:
-                    oc = Octree(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx)
-                    self.value[:n].fill_(0)
-                if index_base + n >= 0xFFFFFFFF:
-                    # the packed frame carries 32-bit global point ids and 0xFFFFFFFF is its "no point" sentinel
-                    raise OverflowError(f"tile {i}: global point id {index_base + n - 1} does not fit the packed frame's 32-bit id "
-                                        "(split the stream into runs of < 2^32 - 1 points)")
-                _lib.check(lib.treee_splat_dev(self.ctx.handle, ptr(xyz), ptr(self.value), n, ptr(view), ptr(proj), env.scale, env.min, env.max,
-                                               self.w, self.h, ptr(self.packed), 1, index_base, None, None))
-                roots.append({"corner": oc.corner.tolist(), "size": oc.size, "points": n, "nodes": int(oc.n_nodes), "lod": int(oc.n_lod)})
-                if on_tile is not None:
-                    on_tile(i, tile, oc, xyz)
-                oc.close()
-            total += n
-            index_base += n
-            i += 1
-        self.compute.synchronize()
-        return {"tiles": roots, "points": total}
 
     def _decoded(self, tiles):
         """passes LAS tiles through; a LAZ tile is handed on once its records are in pinned memory, and the decompression
@@ -196,11 +144,194 @@ class TileStream:
                     if tile.records is self.pinned[k]:
                         self.pinned_read[k].record(self.copy)
 
+
+class TileStream(_Staging):
+    """PER TILE, NO GHOST POINTS (module docstring): every tile its own octree and its own neighbourhoods."""
+
+    def __init__(self, device, max_points, max_stride=20, width=1920, height=1080, knn_k=0, leaf_cap=256, lod_cap=256):
+        self._init_staging(device, max_points, max_stride)
+        torch = self.torch
+        self.ctx = Context(self.device.index, self.compute)
+        self.ctx.reserve(int(max_points * 1.1) * 64 + (64 << 20))
+        # with kNN on, a tile's octree node table is completed on a side stream under the kNN structure's own build
+        self.side = torch.cuda.Stream(self.device) if knn_k else None
+        self.ctx2 = Context(self.device.index, self.side) if knn_k else None
+        if self.ctx2 is not None:
+            self.ctx2.reserve(int(max_points * 1.1) * 24 + (32 << 20))
+        self.xyz = torch.empty((self.max_points, 3), dtype=torch.float32, device=self.device)
+        self.value = torch.empty((self.max_points,), dtype=torch.int32, device=self.device)
+        self.curve = torch.empty((self.max_points,), dtype=torch.float32, device=self.device) if knn_k else None
+        self.packed = torch.empty((height, width), dtype=torch.int64, device=self.device)
+        self.w, self.h, self.knn_k = width, height, int(knn_k)
+        self.leaf_cap, self.lod_cap = leaf_cap, lod_cap
+
+    def run(self, tiles, view, proj, env, on_tile=None):
+        """Streams `tiles` (an iterable of Tile).  Returns a dict with the tile roots (corner, size, node / lod
+        counts per tile) and the totals; the frame is left in self.packed (depth_bits << 32 | global index)."""
+        torch, lib = self.torch, _lib.lib()
+        roots, total, index_base = [], 0, 0
+        it = self._decoded(iter(tiles))
+        pending = next(it, None)
+        if pending is not None:
+            self._upload(pending, 0, first=True)
+        i = 0
+        with torch.cuda.stream(self.compute):
+            # n = 0, accumulate = 0: clears the packed frame (render/src/window.rs:153-159)
+            _lib.check(lib.treee_splat_dev(self.ctx.handle, None, None, 0, ptr(view), ptr(proj), env.scale, env.min, env.max, self.w, self.h,
+                                           ptr(self.packed), 0, 0, None, None))
+        while pending is not None:
+            tile, slot = pending, i & 1
+            pending = next(it, None)
+            if pending is not None:  # next tile's PCIe copy runs under this tile's kernels
+                self._upload(pending, slot ^ 1, first=i == 0)
+            with torch.cuda.stream(self.compute):
+                self.compute.wait_event(self.copied[slot])
+                n = tile.n
+                xyz = self.xyz[:n]
+                _lib.check(lib.treee_decode_las_records_dev(self.ctx.handle, ptr(self.raw[slot]), n, tile.stride, ptr(tile.scale),
+                                                            ptr(tile.offset), ptr(tile.center), ptr(xyz)))
+                self.consumed[slot].record(self.compute)  # the staging buffer may be overwritten from here on
+                if self.knn_k:
+                    oc = Octree(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx, defer=True)
+                    tree = KDTree.from_octree(oc, self.ctx)
+                    oc.complete(self.ctx2)
+                    self.compute.wait_stream(self.side)
+                    tree.curvature_dev(self.knn_k, F32_MAX, self.ctx, out=self.curve[:n])
+                    _lib.check(lib.treee_map_to_u32_dev(self.ctx.handle, ptr(self.curve), n, ptr(self.value)))
+                    tree.close()
+                else:
+                    oc = Octree(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx)
+                    self.value[:n].fill_(0)
+                if index_base + n >= 0xFFFFFFFF:
+                    # the packed frame carries 32-bit global point ids and 0xFFFFFFFF is its "no point" sentinel
+                    raise OverflowError(f"tile {i}: global point id {index_base + n - 1} does not fit the packed frame's 32-bit id "
+                                        "(split the stream into runs of < 2^32 - 1 points)")
+                _lib.check(lib.treee_splat_dev(self.ctx.handle, ptr(xyz), ptr(self.value), n, ptr(view), ptr(proj), env.scale, env.min, env.max,
+                                               self.w, self.h, ptr(self.packed), 1, index_base, None, None))
+                roots.append({"corner": oc.corner.tolist(), "size": oc.size, "points": n, "nodes": int(oc.n_nodes), "lod": int(oc.n_lod)})
+                if on_tile is not None:
+                    on_tile(i, tile, oc, xyz)
+                oc.close()
+            total += n
+            index_base += n
+            i += 1
+        self.compute.synchronize()
+        return {"tiles": roots, "points": total}
+
     def close(self):
         if self.pool is not None:
             self.pool.shutdown()
         if self.ctx2 is not None:
             self.ctx2.close()
+        self.ctx.close()
+
+
+class WholeCloudStream(_Staging):
+    """ONE CLOUD (module docstring): the tiles are decoded into one resident xyz buffer as they arrive -- the PCIe copy of
+    tile i + 1 runs under the decode of tile i --, then the whole path runs ONCE over the concatenation: Morton sort +
+    octree / LOD with one cube (treee_sort_dev / treee_octree_complete_dev on a side stream) [-> kNN structure from that
+    sort -> curvature -> map_to_u32] -> splat of the sorted records -> frame.  Global point index = position in the
+    concatenation (points of earlier tiles first), as in the per-tile mode's frame.
+
+    After `run` the handles stay open for the caller (`self.octree`, `self.tree`, `self.curve`, `self.value`,
+    `self.packed`, `self.xyz[:n]`) until the next `run` or `close`."""
+
+    def __init__(self, device, total_points, max_tile_points, max_stride=20, width=1920, height=1080, knn_k=31, leaf_cap=256, lod_cap=256):
+        self._init_staging(device, max_tile_points, max_stride)
+        torch = self.torch
+        self.capacity = int(total_points)
+        if self.capacity >= (1 << 31):
+            raise OverflowError(f"{self.capacity} points: a cloud holds at most 2^31 - 1 points (include/treee_hip.h)")
+        self.ctx = Context(self.device.index, self.compute)
+        self.side = torch.cuda.Stream(self.device)
+        self.ctx2 = Context(self.device.index, self.side)
+        self.xyz = torch.empty((self.capacity, 3), dtype=torch.float32, device=self.device)
+        self.value = torch.empty((self.capacity,), dtype=torch.int32, device=self.device)
+        self.curve = torch.empty((self.capacity,), dtype=torch.float32, device=self.device) if knn_k else None
+        self.packed = torch.empty((height, width), dtype=torch.int64, device=self.device)
+        self.w, self.h, self.knn_k = width, height, int(knn_k)
+        self.leaf_cap, self.lod_cap = leaf_cap, lod_cap
+        self.octree = self.tree = None
+
+    def _drop(self):
+        for name in ("tree", "octree"):
+            h = getattr(self, name, None)
+            if h is not None:
+                h.close()
+            setattr(self, name, None)
+
+    def run(self, tiles, view, proj, env):
+        """Streams `tiles` into the resident cloud and builds once.  Returns {"points", "tiles", "nodes", "lod", "corner",
+        "size", "stages_ms": {...}} (HIP events on the compute stream; "ingest" = first copy to last decode, i.e. the
+        PCIe-bound part)."""
+        torch, lib = self.torch, _lib.lib()
+        self._drop()
+        ev = {k: torch.cuda.Event(enable_timing=True) for k in ("t0", "ingested", "structure", "knn", "splat")}
+        it = self._decoded(iter(tiles))
+        pending = next(it, None)
+        if pending is not None:
+            self._upload(pending, 0, first=True)
+        base, i, sizes = 0, 0, []
+        ev["t0"].record(self.compute)
+        while pending is not None:
+            tile, slot = pending, i & 1
+            pending = next(it, None)
+            if pending is not None:  # next tile's PCIe copy runs under this tile's decode
+                self._upload(pending, slot ^ 1, first=i == 0)
+            n = tile.n
+            if base + n > self.capacity:
+                raise ValueError(f"tile {i}: {base + n} points exceed the stream's capacity of {self.capacity}")
+            with torch.cuda.stream(self.compute):
+                self.compute.wait_event(self.copied[slot])
+                _lib.check(lib.treee_decode_las_records_dev(self.ctx.handle, ptr(self.raw[slot]), n, tile.stride, ptr(tile.scale),
+                                                            ptr(tile.offset), ptr(tile.center), ptr(self.xyz[base:base + n])))
+                self.consumed[slot].record(self.compute)  # the staging buffer may be overwritten from here on
+            sizes.append(n)
+            base += n
+            i += 1
+        total = base
+        res = {"points": total, "tiles": sizes, "mode": "one cloud: one cube, one octree, neighbours across tile borders"}
+        with torch.cuda.stream(self.compute):
+            ev["ingested"].record(self.compute)
+            # n = 0, accumulate = 0: clears the packed frame (render/src/window.rs:153-159)
+            _lib.check(lib.treee_splat_dev(self.ctx.handle, None, None, 0, ptr(view), ptr(proj), env.scale, env.min, env.max, self.w, self.h,
+                                           ptr(self.packed), 0, 0, None, None))
+            if total == 0:
+                self.compute.synchronize()
+                return res
+            cloud = self.xyz[:total]
+            if self.knn_k:
+                oc = Octree(cloud, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx, defer=True)
+                tree = KDTree.from_octree(oc, self.ctx)
+                oc.complete(self.ctx2)
+                self.compute.wait_stream(self.side)
+                ev["structure"].record(self.compute)
+                tree.curvature_dev(self.knn_k, F32_MAX, self.ctx, out=self.curve[:total])
+                _lib.check(lib.treee_map_to_u32_dev(self.ctx.handle, ptr(self.curve), total, ptr(self.value)))
+                ev["knn"].record(self.compute)
+                _lib.check(lib.treee_splat_knn_dev(self.ctx.handle, tree._h, ptr(self.value), ptr(view), ptr(proj), env.scale, env.min, env.max,
+                                                   self.w, self.h, ptr(self.packed), 1, 0, None, None))
+                self.tree = tree
+            else:
+                oc = Octree(cloud, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx)
+                ev["structure"].record(self.compute)
+                self.value[:total].fill_(0)
+                ev["knn"].record(self.compute)
+                _lib.check(lib.treee_splat_octree_dev(self.ctx.handle, oc._h, ptr(self.value), ptr(view), ptr(proj), env.scale, env.min, env.max,
+                                                      self.w, self.h, ptr(self.packed), 1, 0, None, None))
+            ev["splat"].record(self.compute)
+            self.octree = oc
+        self.compute.synchronize()
+        res.update(nodes=int(oc.n_nodes), lod=int(oc.n_lod), corner=oc.corner.tolist(), size=oc.size)
+        res["stages_ms"] = {"ingest_decode": ev["t0"].elapsed_time(ev["ingested"]), "sort_octree_knn_structure": ev["ingested"].elapsed_time(ev["structure"]),
+                            "knn_curve": ev["structure"].elapsed_time(ev["knn"]), "splat": ev["knn"].elapsed_time(ev["splat"])}
+        return res
+
+    def close(self):
+        self._drop()
+        if self.pool is not None:
+            self.pool.shutdown()
+        self.ctx2.close()
         self.ctx.close()
 
 
