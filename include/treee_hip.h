@@ -332,11 +332,6 @@ int32_t treee_laz_decompress_chunks(const uint8_t *file, uint64_t file_len, cons
                                     const uint16_t *item_versions, uint32_t n_items, const uint64_t *chunk_starts,
                                     const uint64_t *chunk_bytes, const uint64_t *chunk_points, uint64_t n_chunks, uint32_t threads,
                                     uint8_t *dst, uint64_t dst_len);
-/* the other direction, for fixtures and benchmark input (the reference never writes LAZ): an uncompressed LAS image of
- * point format 0-3 -> the LAZ image of the same records in chunks of chunk_size points.  *out_len_out = bytes needed; with
- * cap below it the call fails with TREEE_ERR_INVALID and the caller retries (random records can grow by a few per cent). */
-int32_t treee_laz_encode(const uint8_t *las, uint64_t las_len, uint32_t chunk_size, uint32_t threads, uint8_t *out, uint64_t cap,
-                         uint64_t *out_len_out);
 /* loading.rs:99: key = floor(p.y) as isize */
 int32_t treee_slice_keys(const float *xyz_aos, uint64_t n, int64_t *key_out);
 int32_t treee_slice_keys_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, int64_t *d_key_out);

@@ -1094,6 +1094,7 @@ def test_tile_stream_of_laz_tiles_equals_the_las_stream(T):
     same octrees, same frame, bit for bit"""
     import torch
 
+    import laz_fixture
     from treee_amd import stream, synth
 
     w, h = 320, 200
@@ -1102,7 +1103,7 @@ def test_tile_stream_of_laz_tiles_equals_the_las_stream(T):
         pts, _ = synth.forest_cloud_torch(n, "cuda", plot=15.0, seed=synth.SEED_FOREST + i)
         t = stream.las_tile_from_cloud(pts)
         las.append(stream.Tile(t.records, t.n, t.stride, t.scale, (i * 15.0, 0.0, 0.0), (15.0, 0.0, 5.0)))
-        z = stream.laz_tile_from_cloud(pts, chunk_size=20_000)
+        z = laz_fixture.laz_tile_from_cloud(pts, chunk_size=20_000)
         z.offset, z.center = las[-1].offset, las[-1].center
         assert z.n == n and len(z.src.data) < 0.8 * n * 20
         lazt.append(z)
@@ -1177,7 +1178,8 @@ def test_whole_cloud_stream_is_the_single_call(T, oracle):
     curve1 = single.curvature_dev(31)
     got = ws.curve[:total]
     assert torch.equal(got.view(torch.int32), curve1.view(torch.int32))
-    check_curve_against_the_restated_loop(T, oracle, whole, tree=ws.tree)
+    with torch.cuda.stream(ws.compute):  # (the stream's handles belong to its own HIP stream)
+        check_curve_against_the_restated_loop(T, oracle, whole, tree=ws.tree)
     # the frame: the single splat of the concatenated cloud with those values
     ctx = T.default_context(torch.device("cuda", 0))
     val = T.map_to_u32_dev(curve1, ctx)
@@ -1211,6 +1213,7 @@ def test_whole_cloud_stream_from_laz_tiles(T):
     """the same resident cloud from LAZ tiles (decompressed on host threads one tile ahead) and from a mixed sequence"""
     import torch
 
+    import laz_fixture
     from treee_amd import stream, synth
 
     w, h = 160, 100
@@ -1219,7 +1222,7 @@ def test_whole_cloud_stream_from_laz_tiles(T):
         pts, _ = synth.forest_cloud_torch(n, "cuda", plot=15.0, seed=synth.SEED_FOREST + 60 + i)
         t = stream.las_tile_from_cloud(pts)
         las.append(stream.Tile(t.records, t.n, t.stride, t.scale, (i * 15.0, 0.0, 0.0), (15.0, 0.0, 5.0)))
-        z = stream.laz_tile_from_cloud(pts, chunk_size=7_000)
+        z = laz_fixture.laz_tile_from_cloud(pts, chunk_size=7_000)
         z.offset, z.center = las[-1].offset, las[-1].center
         lazt.append(z)
     cam = T.Camera3D(w / h)
@@ -2104,6 +2107,133 @@ def test_peer_double_refuses_what_real_rccl_would_corrupt(T, tmp_path):
     mp.spawn(_peer_double_misuse_worker, args=(2, str(tmp_path), os.path.join(tmp_path, "uid")), nprocs=2, join=True)
     rc = [int(open(os.path.join(tmp_path, f"rc{r}")).read()) for r in range(2)]
     assert rc[1] != 0 and rc[0] != 0
+
+
+def _stream_order_worker(rank, world, port, out_dir):
+    """the two-stream frame path of bench.py's N > 1 step (draw + MIN all-reduce on the side stream, resolve on the main one)
+    through the library's RCCL transport against the stream-ordered peer double -- once as written, once with the consumer's
+    wait_stream removed, once with the producer's"""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TREEE_RCCL_LIB=_peer_double(), TREEE_DOUBLE_DELAY_MS="40")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import treee_amd as T
+    from treee_amd import distributed as D
+    from treee_amd import synth
+
+    comm = D.Comm.rccl()
+    assert comm.is_rccl and comm.world == world
+    n, plot, w, h = 60_000, 20.0, 320, 180
+    pts, _ = synth.forest_cloud_torch(n, dev, plot=plot, seed=synth.SEED_FOREST + rank, origin=D.tile_origin(rank, world, plot))
+    view = T.view_from_transform(T.rotation_x(-0.6) @ T.translation(0.0, 0.0, 60.0))
+    proj = T.Camera3D(w / h).projection()
+    main, side = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    ctx, ctx2 = T.Context(dev, main), T.Context(dev, side)
+    out = {}
+    for variant in ("as_written", "consumer_does_not_wait", "producer_is_not_waited_for", "as_written_again"):
+        packed = torch.full((h, w), -1, dtype=torch.int64, device=dev)
+        depth = torch.empty((h, w), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        with torch.cuda.stream(main):
+            if variant == "producer_is_not_waited_for":
+                # the frame is drawn on the MAIN stream behind a long kernel; the side stream reduces it without waiting
+                torch.cuda._sleep(300_000_000)
+                T._lib.check(T.lib().treee_splat_dev(ctx.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h,
+                                                     T.context.ptr(packed), 0, rank * n, None, None))
+            else:
+                side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if variant != "producer_is_not_waited_for":
+                T._lib.check(T.lib().treee_splat_dev(ctx2.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h,
+                                                     T.context.ptr(packed), 0, rank * n, None, None))
+            D.frame_reduce_min(packed, comm, ctx2)
+        with torch.cuda.stream(main):
+            if variant != "consumer_does_not_wait":
+                main.wait_stream(side)
+            T._lib.check(T.lib().treee_splat_resolve_dev(ctx.handle, T.context.ptr(packed), None, 0, w, h, T.context.ptr(depth), None))
+            got = depth.clone()
+        torch.cuda.synchronize()
+        out[variant] = got.cpu()
+        out[variant + "_packed_after"] = packed.cpu()
+    # what the reduced frame must be: the element-wise minimum of the two ranks' own frames, exchanged over gloo
+    own = torch.empty((h, w), dtype=torch.int64, device=dev)
+    c0 = T.default_context(dev)
+    T._lib.check(T.lib().treee_splat_dev(c0.handle, T.context.ptr(pts), None, n, T.context.ptr(view), T.context.ptr(proj), 0.3, 0, 0xFFFFFFFF, w, h,
+                                         T.context.ptr(own), 0, rank * n, None, None))
+    torch.cuda.synchronize()
+    both = [torch.empty((h, w), dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(both, own.cpu())
+    out["expected_packed"] = torch.minimum(both[0], both[1])  # (depth < 1.0: the words are below 2^63, the signed order is the unsigned one)
+    torch.save(out, os.path.join(out_dir, f"order{rank}.pt"))
+    ctx.close()
+    ctx2.close()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def test_peer_double_exposes_a_missing_stream_wait(T, tmp_path):
+    """the stand-in for librccl has RCCL's stream semantics -- nothing is in place when a call returns, the
+    transfers are ordered on the stream they were given -- so a stream-ORDER mistake between the two streams that share the
+    communicator is SEEN: the two-stream frame path as written gives the reduced frame; without the consumer's wait_stream the
+    main stream resolves a frame the reduction has not reached, without the producer's the reduction ships a frame that has not
+    been drawn.  (With the double of rounds 3-4, which drained the stream around every call, the first mistake passed.)"""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_stream_order_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"order{r}.pt")) for r in range(2)]
+    expected = res[0]["expected_packed"]
+    assert torch.equal(expected, res[1]["expected_packed"]) and int((expected >> 32 < 0x3F800000).sum()) > 1000
+    exp_depth = (expected >> 32).to(torch.int32).view(torch.float32)
+    for r in range(2):
+        for v in ("as_written", "as_written_again"):
+            assert torch.equal(res[r][v + "_packed_after"], expected), (r, v)
+            assert torch.equal(res[r][v].view(torch.int32), exp_depth.view(torch.int32)), (r, v)
+        # the mistakes are visible: the resolved frame is NOT the reduced one ...
+        assert not torch.equal(res[r]["consumer_does_not_wait"].view(torch.int32), exp_depth.view(torch.int32)), r
+        # ... although the reduction itself was right in that variant (only its consumer was early)
+        assert torch.equal(res[r]["consumer_does_not_wait_packed_after"], expected), r
+        assert not torch.equal(res[r]["producer_is_not_waited_for_packed_after"], expected), r
+
+
+@pytest.mark.parametrize("transport", ["host", "rccl"])
+def test_bench_two_ranks_on_one_gpu_prints_the_whole_line(T, transport):
+    """`python3 bench.py --gpus 2` (the ranks spawned by bench.py itself, both on this GPU, torch group over gloo) prints ONE
+    JSON line that carries everything the contract asks of any N: roofline, cpu_baseline (rank 0, after the ranks have
+    parted), the communicator's own rank count.  transport "rccl": the library's RCCL transport against the stream-ordered
+    peer double -- the step's two-stream frame path (draw + reduce on the side stream, resolve on the main one) with a
+    transport that completes nothing before the stream says so; the halo check compares neighbours across the shards."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TREEE_BENCH_BACKEND="gloo", TREEE_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    if transport == "rccl":
+        env["TREEE_RCCL_LIB"] = _peer_double()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--points", "1000000", "--plot", "52", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "60000", "--transport", transport], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["comm_ranks"] == 2 and d["config"]["halo_verified"] is True
+    assert d["config"]["transport"] == ("rccl" if transport == "rccl" else "host-staged callbacks over the torch group")
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
+    assert d["hbm_copy_GBps"] > 100
 
 
 def test_rccl_transport_with_one_rank(T, oracle):

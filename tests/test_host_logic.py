@@ -452,6 +452,53 @@ def _rccl_agreement_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _side_group_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from treee_amd import _lib
+    from treee_amd import distributed as D
+
+    # what an nccl-only default group looks like to Comm.host: "cannot carry host tensors".  (No RCCL group of two ranks can
+    # be formed here or on a one-GPU box; the branch under test is the one ADVICE r4 found broken: the callbacks of the
+    # fallback must not ride on that group.)
+    made = []
+    real_new_group = dist.new_group
+    D._cannot_carry_host_tensors = lambda group=None: group is None or group is dist.group.WORLD
+    dist.new_group = lambda *a, **k: made.append(k.get("backend")) or real_new_group(*a, **k)
+    comm = D.Comm.host()
+    dist.new_group = real_new_group
+    # the library's plan arithmetic needs an all-gather through the communicator's callbacks: run one through the C ABI
+    import ctypes as C
+
+    send = np.full(8, 100 + rank, np.uint8)
+    recv = np.zeros(8 * world, np.uint8)
+    rc = comm._keep.all_gather(None, send.ctypes.data_as(C.c_void_p), recv.ctypes.data_as(C.c_void_p), 8)
+    buf = np.array([5 + rank, 9 - rank], np.uint64)
+    rc2 = comm._keep.all_reduce_min_u64(None, buf.ctypes.data_as(C.POINTER(C.c_uint64)), 2)
+    sub_error = None
+    try:
+        D.Comm.host(real_new_group(ranks=[0, 1], backend="gloo"))  # a sub-group the check calls device-only is refused, not wrapped
+    except _lib.TreeeError as e:
+        sub_error = str(e)
+    torch.save({"made": made, "rc": (rc, rc2), "recv": recv, "min": buf, "info": comm.info(), "sub_error": sub_error}, os.path.join(out_dir, f"s{rank}.pt"))
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_host_transport_under_a_device_only_group_gets_a_gloo_side_group(tmp_path):
+    """Comm.auto's fallback under `init_process_group("nccl")` handed host buffers to a group that only
+    moves device tensors.  Comm.host now gives its callbacks a gloo group over the same ranks (collectively, on the default
+    group) and refuses a device-only SUB-group with a clear error."""
+    world = 2
+    mp.spawn(_side_group_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(tmp_path, f"s{r}.pt"), weights_only=False)
+        assert res["made"] == ["gloo"] and res["rc"] == (0, 0) and res["info"] == (r, 2, False)
+        assert res["recv"].tolist() == [100] * 8 + [101] * 8 and res["min"].tolist() == [5, 8]
+        assert res["sub_error"] is None  # (the patched check only flags the default group: a gloo sub-group passes)
+
+
 def test_ranks_agree_on_the_transport_before_any_collective_init(tmp_path):
     """one rank cannot open librccl.  Every rank probes for itself (treee_rccl_available: no collective),
     the flags are MIN-reduced, and ALL ranks raise / fall back together -- nobody waits in a broadcast or inside

@@ -182,10 +182,10 @@ def test_laz_round_trip_of_noise_and_extremes(T, fmt, rl):
 
 @pytest.mark.parametrize("fmt,rl", [(0, 20), (1, 28), (2, 26), (3, 34), (3, 41)])
 def test_library_encoder_writes_the_bytes_of_the_independent_one(T, fmt, rl):
-    """treee_laz_encode (C++, fixtures / benchmark input) against oracle/laz_encoder.py (Python): the same file, byte for
+    """the C++ fixture compressor (tests/cpp/laz_encode_fixture.cpp: fixtures / benchmark input) against oracle/laz_encoder.py (Python): the same file, byte for
     byte -- three statements of the format (two encoders, one decoder) agree.  Then noise, which needs the retry path."""
     from oracle import laz_encoder as E
-    from treee_amd.laz import laz_encode
+    from laz_fixture import laz_encode
 
     rec = np.concatenate([flight_lines(1_700, 40 + fmt, fmt, rl), np.random.default_rng(fmt).integers(0, 256, (300, rl), dtype=np.uint8)])
     las = las_image(T, rec, fmt)
@@ -263,7 +263,7 @@ def test_laz_golden_fixture(T):
     """tests/golden/laz_fmt3.npz (make_laz_golden.py): the committed LAZ image decodes to the committed records, and both
     encoders still write exactly that image"""
     from oracle import laz_encoder as E
-    from treee_amd.laz import laz_encode
+    from laz_fixture import laz_encode
 
     g = np.load(os.path.join(ROOT, "tests", "golden", "laz_fmt3.npz"))
     laz, las, rec = g["laz"].tobytes(), g["las"].tobytes(), g["records"]

@@ -114,7 +114,6 @@ SYMBOLS = {
     "treee_slice_keys_dev": (_i32, [_vp, _vp, _u64, _vp]),
     "treee_laz_chunk_table": (_i32, [_vp, _u64, _u64, _u32, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
     "treee_laz_decompress_chunks": (_i32, [_vp, _u64, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u64, _u32, _vp, _u64]),
-    "treee_laz_encode": (_i32, [_vp, _u64, _u32, _u32, _vp, _u64, C.POINTER(_u64)]),
     "treee_slice_bin": (_i32, [_vp, _u64, C.POINTER(C.c_int64), C.POINTER(_u64), _vp, _vp, _u64]),
     "treee_slice_bin_dev": (_i32, [_vp, _vp, _u64, C.POINTER(C.c_int64), C.POINTER(_u64), _vp, _vp, _u64]),
     "treee_select_xz_dev": (_i32, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),

@@ -133,6 +133,14 @@ class Comm:
 
         live = dist.is_initialized()
         rank, world = (dist.get_rank(group), dist.get_world_size(group)) if live else (0, 1)
+        if live and world > 1 and _cannot_carry_host_tensors(group):
+            # an nccl(= RCCL)-only group moves device tensors only, and these callbacks hand it host buffers (the
+            # fallback of Comm.auto under `init_process_group("nccl")` built a communicator whose every collective failed
+            # inside the callback).  The callbacks get a gloo group over the same ranks.  new_group is collective over the
+            # DEFAULT group, so this is only done for it; a caller with an nccl sub-group passes a gloo group of its own.
+            if group is not None and group is not dist.group.WORLD:
+                raise _lib.TreeeError(_lib.TREEE_ERR_UNSUPPORTED, "Comm.host: the group's backend cannot move host tensors; pass a gloo group over the same ranks")
+            group = dist.new_group(backend="gloo")
 
         def view(p, nbytes):
             return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 1),))[: int(nbytes)]
@@ -324,6 +332,11 @@ def frame_reduce_min(packed, comm, ctx=None):
     c = ctx or default_context(packed.device)
     _lib.check(_lib.lib().treee_frame_reduce_min_dev(c.handle, comm.handle, ptr(packed), packed.numel()))
     return packed
+
+
+def _cannot_carry_host_tensors(group=None):
+    """True for a group whose backend only moves device tensors (nccl = RCCL)"""
+    return dist.get_backend(group) == "nccl"
 
 
 def _global(group, r):

@@ -189,22 +189,6 @@ class Laz:
             cb(Chunk(self.data[s : s + l * self.point_length], self.point_length, self.offset, self.scale, self.center))
 
 
-def laz_encode(las_image, chunk_size=DEFAULT_CHUNK_SIZE, threads=0):
-    """An uncompressed LAS image (point format 0-3) -> the LAZ image of the same records (treee_laz_encode): fixtures and
-    benchmark input; the reference only reads LAZ."""
-    import ctypes as C
-
-    src = np.frombuffer(las_image, np.uint8)
-    need = C.c_uint64(0)
-    out = np.zeros(len(src) + len(src) // 8 + 4096, np.uint8)
-    rc = _lib.lib().treee_laz_encode(ptr(src), len(src), chunk_size, threads, ptr(out), len(out), C.byref(need))
-    if rc != 0 and need.value > len(out):  # (noise that grew: once more with the room it asked for)
-        out = np.zeros(need.value, np.uint8)
-        rc = _lib.lib().treee_laz_encode(ptr(src), len(src), chunk_size, threads, ptr(out), len(out), C.byref(need))
-    _lib.check(rc)
-    return out[: need.value].tobytes()
-
-
 def slice_keys(points, ctx=None):
     """loading.rs:99: idx = p.y.floor() as isize."""
     if is_device(points):

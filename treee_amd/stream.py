@@ -349,18 +349,3 @@ def las_tile_from_cloud(xyz, scale=0.001, stride=20, pin=True):
     host = torch.empty((n * stride,), dtype=torch.uint8, pin_memory=pin)
     host.copy_(rec.view(torch.uint8).reshape(-1))
     return Tile(host, n, stride, (scale,) * 3, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
-
-
-def laz_tile_from_cloud(xyz, scale=0.001, stride=20, chunk_size=50_000, threads=0):
-    """the same records as las_tile_from_cloud, LAZ-compressed (treee_laz_encode) -- a LazTile"""
-    import struct
-
-    from .laz import laz_encode
-    from .synth import las_bytes
-
-    t = las_tile_from_cloud(xyz, scale, stride, pin=False)
-    img = bytearray(las_bytes(np.zeros((t.n, 3), np.int32), scale=(scale,) * 3, fmt=0, record_length=stride))
-    (off,) = struct.unpack_from("<I", img, 96)
-    img[off:] = t.records.numpy().tobytes()
-    struct.pack_into("<6d", img, 179, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)  # (bbox unused here: the tile's centre is passed explicitly)
-    return LazTile(laz_encode(bytes(img), chunk_size=chunk_size, threads=threads), center=(0.0, 0.0, 0.0))
