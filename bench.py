@@ -684,7 +684,12 @@ def out_of_core_stage(dev, n, proj, tiles=67):
     try:
         torch.cuda.empty_cache()
         ws = stream.WholeCloudStream(dev, n * tiles, n, width=W, height=H, knn_k=K)
-        ws.run(gen(3), view, proj, env)
+        # two full runs: the first touches 130 GB of freshly allocated HBM (the resident cloud, both sorted copies, the node
+        # table ...), which is several times slower than reusing it -- reported as first_run_seconds; `seconds` is the second
+        # run, the state a resident service is in (the library's pool keeps the arrays: csrc/common.h pool_idle_limit)
+        t0 = time.perf_counter()
+        ws.run(gen(tiles), view, proj, env)
+        first = time.perf_counter() - t0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         r = ws.run(gen(tiles), view, proj, env)
@@ -692,7 +697,7 @@ def out_of_core_stage(dev, n, proj, tiles=67):
         st = r["stages_ms"]
         b_struct, b_knn = BYTES["keys_sort_octree_knn_structure"], BYTES["knn_curve"]
         res["whole_cloud"] = {
-            "mode": r["mode"], "points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1),
+            "mode": r["mode"], "points": r["points"], "seconds": round(dt, 3), "Mpoints_per_s": round(r["points"] / dt / 1e6, 1), "first_run_seconds": round(first, 3),
             "pcie_GBps_during_ingest": round(r["points"] * 20 / (st["ingest_decode"] * 1e-3) / 1e9, 1),
             "stages_ms": {k: round(v, 2) for k, v in st.items()}, "octree_nodes": r["nodes"], "lod_entries": r["lod"], "cube_size_m": round(r["size"], 1),
             "knn_curve_frac_of_hbm": round(b_knn * r["points"] / (st["knn_curve"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

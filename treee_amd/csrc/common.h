@@ -136,6 +136,23 @@ __device__ __forceinline__ uint32_t hilbert_of_morton_lut(uint32_t key, const ui
 	return h;
 }
 
+// Ten further levels of the same curve: the index digits of a point's LOW Morton key (the 2^-20 sub-cells inside its 2^-10
+// cell) continued from the state the cell's own ten levels leave the machine in -- the low 30 bits of the 60-bit Hilbert index
+// whose high 30 bits hilbert_of_morton gives.  Ordering a crowded cell's points by it keeps a run of consecutive points one
+// compact blob at every scale, where the low Morton key itself (rounds 1-4) brings the Z curve's jumps back inside the cell.
+__device__ __forceinline__ uint32_t hilbert_low_of_morton_lut(uint32_t key_hi, uint32_t key_lo, const uint16_t *lut) {
+	uint32_t s = 0, h = 0;
+#pragma unroll
+	for (int sh = 27; sh >= 0; sh -= 3) s = lut[s + ((key_hi >> sh) & 7u)] >> 3;
+#pragma unroll
+	for (int sh = 27; sh >= 0; sh -= 3) {
+		const uint32_t e = lut[s + ((key_lo >> sh) & 7u)];
+		h = (h << 3) | (e & 7u);
+		s = e >> 3;
+	}
+	return h;
+}
+
 // Morton key pieces (definition: oracle/octree_oracle.cpp): q = clamp(floor(((p - c) / size) * 1024), 0, 1023), NaN -> 0
 __device__ __forceinline__ uint32_t quant10(float p, float c, float size) {
 	float t = ((p - c) / size) * 1024.0f; // IEEE divide (hipcc default is correctly rounded)
@@ -212,6 +229,10 @@ struct treee_ctx {
 		size_t cap;
 	};
 	std::vector<PoolBlock> pool_idle;
+	// idle bytes kept before the oldest blocks go back to the driver: 8 GiB, or a quarter of the device's memory when that is
+	// more (72 GB of an MI355X) -- the arrays of a 1 G-point cloud are 4 - 16 GB EACH, and a block that comes back from
+	// hipMalloc fresh is slow at its first touch (kNN over 1.005 G points: 2.7 s on fresh arrays, 0.52 s on reused ones)
+	size_t pool_idle_limit = size_t(8) << 30;
 	std::unordered_map<void *, size_t> pool_live;
 	std::mutex pool_mu;
 

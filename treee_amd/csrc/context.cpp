@@ -37,7 +37,6 @@ int32_t set_err(int32_t code, const char *fmt, ...) {
 static std::mutex g_live_mu; // contexts that are still alive (handles may outlive their context)
 static std::set<treee_ctx *> g_live;
 constexpr size_t POOL_GRANULE = size_t(1) << 20;
-constexpr size_t POOL_IDLE_LIMIT = size_t(8) << 30; // idle bytes kept per context before trimming
 
 int32_t pool_alloc(treee_ctx *ctx, size_t bytes, void **out) {
 	bytes = ((bytes ? bytes : 1) + POOL_GRANULE - 1) & ~(POOL_GRANULE - 1);
@@ -68,6 +67,17 @@ int32_t pool_alloc(treee_ctx *ctx, size_t bytes, void **out) {
 			ctx->pool_idle.clear();
 		}
 		e = hipMalloc(&p, bytes);
+		if (e != hipSuccess) { // the other contexts of this device keep idle blocks too (up to pool_idle_limit each)
+			(void)hipDeviceSynchronize();
+			std::lock_guard<std::mutex> live(g_live_mu);
+			for (treee_ctx *other : g_live) {
+				if (other == ctx || other->device != ctx->device) continue;
+				std::lock_guard<std::mutex> lk(other->pool_mu);
+				for (auto &b : other->pool_idle) (void)hipFree(b.p);
+				other->pool_idle.clear();
+			}
+			e = hipMalloc(&p, bytes);
+		}
 		if (e != hipSuccess) return set_err(TREEE_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
 	}
 	std::lock_guard<std::mutex> lk(ctx->pool_mu);
@@ -87,7 +97,7 @@ void pool_release(treee_ctx *ctx, void *p) {
 			ctx->pool_live.erase(it);
 			size_t idle = 0;
 			for (auto &b : ctx->pool_idle) idle += b.cap;
-			while (idle > POOL_IDLE_LIMIT && !ctx->pool_idle.empty()) { // trim oldest first
+			while (idle > ctx->pool_idle_limit && !ctx->pool_idle.empty()) { // trim oldest first
 				(void)hipStreamSynchronize(ctx->stream);
 				idle -= ctx->pool_idle.front().cap;
 				(void)hipFree(ctx->pool_idle.front().p);
@@ -318,7 +328,10 @@ int32_t treee_ctx_create(int32_t device, void *hip_stream, treee_ctx **out) {
 	c->stream = (hipStream_t)hip_stream;
 	c->own_stream = false;
 	hipDeviceProp_t prop;
-	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+		c->num_cus = prop.multiProcessorCount;
+		if (prop.totalGlobalMem / 4 > c->pool_idle_limit) c->pool_idle_limit = prop.totalGlobalMem / 4;
+	}
 	e = hipHostMalloc((void **)&c->h_scalars, 64 * sizeof(uint32_t), hipHostMallocDefault);
 	if (e != hipSuccess) {
 		delete c;

@@ -1433,19 +1433,34 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {
 	v = (v | (v << 2)) & 0x09249249u;
 	return v;
 }
-__global__ __launch_bounds__(256) void k_fine_keys(const float4 *__restrict__ rec, uint32_t n, float cx, float cy, float cz, float size,
+// `hil`: the low key as the continuation of the cell's Hilbert index (hilbert_low_of_morton_lut) instead of the low Morton key
+__global__ __launch_bounds__(256) void k_fine_keys(const float4 *__restrict__ rec, uint32_t n, float cx, float cy, float cz, float size, bool hil,
                                                     uint32_t *__restrict__ lo) {
+	__shared__ uint16_t s_lut[24 * 8];
+	if (threadIdx.x < 24 * 8) {
+		constexpr uint16_t LUT[24 * 8] = {TREEE_HILBERT_LUT_INIT};
+		s_lut[threadIdx.x] = LUT[threadIdx.x];
+	}
+	__syncthreads();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
 	const float4 p = rec[i];
-	lo[i] = spread10(quant_lo10(p.x, cx, size)) | (spread10(quant_lo10(p.y, cy, size)) << 1) | (spread10(quant_lo10(p.z, cz, size)) << 2);
+	const uint32_t m = spread10(quant_lo10(p.x, cx, size)) | (spread10(quant_lo10(p.y, cy, size)) << 1) | (spread10(quant_lo10(p.z, cz, size)) << 2);
+	lo[i] = hil ? hilbert_low_of_morton_lut(morton30(p.x, p.y, p.z, cx, cy, cz, size), m, s_lut) : m;
 }
-__global__ __launch_bounds__(256) void k_fine_keys_aos(const float *__restrict__ xyz, uint32_t n, float cx, float cy, float cz, float size,
+__global__ __launch_bounds__(256) void k_fine_keys_aos(const float *__restrict__ xyz, uint32_t n, float cx, float cy, float cz, float size, bool hil,
                                                         uint32_t *__restrict__ lo) {
+	__shared__ uint16_t s_lut[24 * 8];
+	if (threadIdx.x < 24 * 8) {
+		constexpr uint16_t LUT[24 * 8] = {TREEE_HILBERT_LUT_INIT};
+		s_lut[threadIdx.x] = LUT[threadIdx.x];
+	}
+	__syncthreads();
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 	if (i >= n) return;
-	lo[i] = spread10(quant_lo10(xyz[3ull * i + 0], cx, size)) | (spread10(quant_lo10(xyz[3ull * i + 1], cy, size)) << 1) |
-	        (spread10(quant_lo10(xyz[3ull * i + 2], cz, size)) << 2);
+	const float x = xyz[3ull * i + 0], y = xyz[3ull * i + 1], z = xyz[3ull * i + 2];
+	const uint32_t m = spread10(quant_lo10(x, cx, size)) | (spread10(quant_lo10(y, cy, size)) << 1) | (spread10(quant_lo10(z, cz, size)) << 2);
+	lo[i] = hil ? hilbert_low_of_morton_lut(morton30(x, y, z, cx, cy, cz, size), m, s_lut) : m;
 }
 __global__ __launch_bounds__(256) void k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
 	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -1873,8 +1888,9 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 		TREEE_TRY(ctx->alloc_t(n, &d_lo));
 		TREEE_TRY(ctx->alloc_t(n, &d_lo_s));
 		TREEE_TRY(ctx->alloc_t(n, &d_pos1));
+		static const bool fine_morton = getenv("TREEE_KNN_FINE_MORTON") != nullptr; // A/B hook: the low Morton key of rounds 1-4
 		hipLaunchKernelGGL(k_fine_keys, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_sorted, (uint32_t)n, sc->corner[0], sc->corner[1], sc->corner[2],
-		                   sc->size, d_lo);
+		                   sc->size, !fine_morton && !morton_order, d_lo);
 		TREEE_LAUNCH_CHECK();
 		TREEE_TRY(sort_pairs_dev(ctx, d_lo, nullptr, n, 30, d_lo_s, d_pos1));
 		d_first = d_pos1;
@@ -2029,8 +2045,9 @@ int32_t build_segmented(treee_ctx *ctx, const float *d_xyz, const uint32_t *d_se
 		}
 		if (flag) {
 			uint32_t *d_lo = d_sk, *d_lo_s = d_sks, *d_pos1 = d_perm2, *d_hi = d_keys; // buffers that are free at this point
+			static const bool fine_morton = getenv("TREEE_KNN_FINE_MORTON") != nullptr; // A/B hook
 			hipLaunchKernelGGL(k_fine_keys_aos, dim3(div_up(n, 256)), dim3(256), 0, st, d_xyz, (uint32_t)n, sc->corner[0], sc->corner[1], sc->corner[2],
-			                   sc->size, d_lo);
+			                   sc->size, !fine_morton && !morton_order, d_lo);
 			TREEE_LAUNCH_CHECK();
 			TREEE_TRY(sort_pairs_dev(ctx, d_lo, nullptr, n, 30, d_lo_s, d_pos1));
 			hipLaunchKernelGGL(k_gather_u32, dim3(div_up(n, 256)), dim3(256), 0, st, d_keys_raw, d_pos1, (uint32_t)n, d_hi);
