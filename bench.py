@@ -53,6 +53,9 @@ def parse():
                     "(configs[3]: 150000000); overrides --points / --plot")
     ap.add_argument("--transport", choices=["auto", "rccl", "host"], default="auto", help="N > 1: the library's RCCL communicator (default under nccl) or "
                     "host callbacks over the torch group")
+    ap.add_argument("--stream-tiles", action="store_true", help="configs[4]'s form of a step: every rank's points arrive as LAS tiles of <= 15 M records (20 B) in pinned "
+                    "host memory and are decoded into the rank's resident cloud at the START OF EVERY STEP (PCIe-inclusive; the copy of tile i + 1 under the "
+                    "decode of tile i), then the step runs as usual: --gpus 8 --total-points 1005000000 --stream-tiles")
     ap.add_argument("--plot", type=float, default=PLOT, help="edge of the square tile in metres (632 with --points 150000000 keeps the density)")
     ap.add_argument("--halo", type=float, default=2.0)
     ap.add_argument("--splat-unsorted", action="store_true", help="draw the caller's cloud fragment by fragment (treee_splat_dev, rounds 1-2) instead of "
@@ -157,6 +160,16 @@ def main():
     origin = D.tile_origin(rank, world, plot)
     bounds = D.tile_bounds(rank, world, plot)
     pts, seg = synth.forest_cloud_torch(n, dev, plot=plot, seed=synth.SEED_FOREST + rank, origin=origin)
+    ingest = None
+    if args.stream_tiles:
+        from treee_amd import stream
+
+        tile_points = 15_000_000
+        tiles = stream.split_into_las_tiles(pts, tile_points)
+        ingest = stream.TileIngest(dev, n, tile_points)
+        del pts
+        ingest.ingest(tiles)
+        pts = ingest.xyz[:n]  # the resident cloud: rewritten (with the same records) by every step's ingest
     cam = T.Camera3D(W / H)
     proj = cam.projection()
     span = plot * max(D.tile_grid(world))
@@ -191,6 +204,8 @@ def main():
     def step(record):
         nonlocal halo
         free_state()  # previous step's handles: blocks return to the context pool, stream-ordered, no sync
+        if ingest is not None:
+            stages.run("ingest_decode_pcie", lambda: ingest.ingest(tiles), record)
         if world > 1:
             return step_sharded(record)
         # ONE Morton sort per step, two consumers: the kNN structure (its own Hilbert re-sort + box tree) is built on this
@@ -261,6 +276,7 @@ def main():
         # ONE Morton sort of the tile per step, as at N = 1: the sharded octree has the own points in Morton order of the
         # common cube; the kNN structure merges the ghosts in with its own (Hilbert) sort (treee_knn_from_shard_dev)
         tree = stages.run("knn_build", lambda: T.KDTree.from_shard(oc, cloud[n:], ctx), record)
+        oc.release_local()  # (the rank's own sorted copy has served: 24 B per point back to the pool before the kNN kernel runs)
         cv = curve[:m] if m <= curve.shape[0] else torch.empty((m,), dtype=torch.float32, device=dev)
         # only the shard's own points are queried: the ghosts behind them are neighbours, not queries
         stages.run("knn_curve", lambda: tree.curvature_dev(K, F32_MAX, ctx, out=cv, n_own=n), record)
@@ -365,6 +381,8 @@ def main():
                 "launched_by": "bench.py (spawned its own ranks)" if os.environ.get("TREEE_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "python"),
                 "total_points": n * world,
                 "halo_verified": halo_verified,
+                "input": (f"streamed every step: {len(tiles)} LAS tiles of <= {tile_points} records (20 B) per rank from pinned host memory, decoded into the rank's "
+                          "resident cloud (PCIe-inclusive)") if ingest is not None else "resident in HBM before the timed region",
             },
             "roofline": {
                 "kernel": "k_knn (kNN k=31 + covariance/eigen -> curve)",
@@ -429,12 +447,18 @@ def dry_run(args, rank, world, backend):
         counts = t.numpy().view(np.uint32)
     plan = D.ShardPlan(counts, 1)
     owned = [int(plan.rank(r).count) for r in range(world)]
+    stream_plan = None
+    if args.stream_tiles:  # what `--stream-tiles` would hand every rank (pure arithmetic: no tile is built without a device)
+        n_rank = (args.total_points // world) if args.total_points else args.points
+        full, rest = divmod(n_rank, 15_000_000)
+        stream_plan = {"points_per_rank": n_rank, "tiles_per_rank": full + (1 if rest else 0), "tile_points": [15_000_000] * full + ([rest] if rest else []),
+                       "pinned_host_bytes_per_rank": n_rank * 20, "total_points": n_rank * world}
     plan.close()
     comm.close()
     if rank == 0:
         print(json.dumps({"dry_run": True, "metric": "Mpoints/s octree+kNN+splat", "value": None, "unit": "Mpoints/s", "n_gpus": world,
                           "config": {"parallelism": f"spatial x/z tiles {D.tile_grid(world)[0]}x{D.tile_grid(world)[1]}", "comm_ranks": info[1],
-                                     "transport": "host-staged callbacks over the torch group", "owned_points_per_rank": owned,
+                                     "transport": "host-staged callbacks over the torch group", "owned_points_per_rank": owned, "stream_tiles": stream_plan,
                                      "launched_by": "bench.py (spawned its own ranks)" if os.environ.get("TREEE_BENCH_SPAWNED") else "torch.distributed.run"}}), flush=True)
     if world > 1:
         dist.barrier()

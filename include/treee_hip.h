@@ -98,6 +98,10 @@ int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_k
  * order inside distance ties -- are those of the whole cloud's cube.  Serves treee_curvature_own_dev / treee_knn_self_dev
  * and position queries.  No reference counterpart (the reference is one process). */
 int32_t treee_knn_from_shard_dev(treee_ctx *ctx, const treee_octree *o, const float *d_ghost_xyz_aos, uint64_t n_ghosts, treee_knn **out);
+/* A sharded octree whose points changed hands keeps the rank's OWN input in Morton order (24 B per point) for the call above.
+ * Once the kNN structure is built -- or if none will be -- give it back; treee_knn_from_shard_dev then fails with
+ * TREEE_ERR_INVALID for this handle.  Everything else about the octree is unaffected. */
+int32_t treee_shard_octree_release_local(treee_octree *o);
 /* One structure for a cloud that is cut into segments the way the reference holds it after segmentation
  * (`segment: Vec<u32>` beside the points, treee/src/calculations.rs:97-118): every segment behaves as its own
  * KDTree::new(&segment_points) (calculations.rs:329, 392-403) -- a self query only ever returns points of the

@@ -1750,6 +1750,7 @@ def _shard_worker(rank, world, port, out_dir, backend="gloo"):
     # double: as gloo, but the library's RCCL transport runs against tests/cpp/rccl_peer_double.cpp (a peer on a one-GPU box)
     if backend == "double":
         os.environ["TREEE_RCCL_LIB"] = _peer_double()
+        os.environ["TREEE_RCCL_LIB_IS_TEST_DOUBLE"] = "1"
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
     if backend == "nccl":
@@ -1949,6 +1950,7 @@ def _sharded_octree_worker(rank, world, port, out_dir, layout, top_level, transp
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if transport == "double":  # the library's RCCL transport against a peer that checks what it is sent (tests/cpp/rccl_peer_double.cpp)
         os.environ["TREEE_RCCL_LIB"] = _peer_double()
+        os.environ["TREEE_RCCL_LIB_IS_TEST_DOUBLE"] = "1"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import treee_amd as T
@@ -2118,7 +2120,7 @@ def _stream_order_worker(rank, world, port, out_dir):
     import torch
     import torch.distributed as dist
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TREEE_RCCL_LIB=_peer_double(), TREEE_DOUBLE_DELAY_MS="40")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TREEE_RCCL_LIB=_peer_double(), TREEE_RCCL_LIB_IS_TEST_DOUBLE="1", TREEE_DOUBLE_DELAY_MS="40")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -2207,8 +2209,8 @@ def test_peer_double_exposes_a_missing_stream_wait(T, tmp_path):
         assert not torch.equal(res[r]["producer_is_not_waited_for_packed_after"], expected), r
 
 
-@pytest.mark.parametrize("transport", ["host", "rccl"])
-def test_bench_two_ranks_on_one_gpu_prints_the_whole_line(T, transport):
+@pytest.mark.parametrize("transport,streamed", [("host", True), ("rccl", False)])
+def test_bench_two_ranks_on_one_gpu_prints_the_whole_line(T, transport, streamed):
     """`python3 bench.py --gpus 2` (the ranks spawned by bench.py itself, both on this GPU, torch group over gloo) prints ONE
     JSON line that carries everything the contract asks of any N: roofline, cpu_baseline (rank 0, after the ranks have
     parted), the communicator's own rank count.  transport "rccl": the library's RCCL transport against the stream-ordered
@@ -2223,8 +2225,9 @@ def test_bench_two_ranks_on_one_gpu_prints_the_whole_line(T, transport):
     env.pop("WORLD_SIZE", None)
     if transport == "rccl":
         env["TREEE_RCCL_LIB"] = _peer_double()
+        env["TREEE_RCCL_LIB_IS_TEST_DOUBLE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--points", "1000000", "--plot", "52", "--steps", "2", "--warmup", "1",
-                        "--cpu-sample", "60000", "--transport", transport], capture_output=True, text=True, timeout=900, env=env)
+                        "--cpu-sample", "60000", "--transport", transport] + (["--stream-tiles"] if streamed else []), capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -2234,6 +2237,47 @@ def test_bench_two_ranks_on_one_gpu_prints_the_whole_line(T, transport):
     assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] == "port"
     assert d["hbm_copy_GBps"] > 100
+    # configs[4]'s form: every rank's points arrive as LAS tiles from pinned host memory at the start of every step
+    assert ("streamed every step" in d["config"]["input"]) == streamed and (("ingest_decode_pcie" in d["stages"]) == streamed)
+
+
+def test_knn_from_a_shard_without_own_points_and_release_of_the_local_copy(T, oracle):
+    """a rank that owns nothing but has ghost points (n_own == 0, g > 0: the in-place key conversion of the ghosts
+    starts at offset 0), and the hand-back of the rank's own sorted copy (treee_shard_octree_release_local)."""
+    import torch
+
+    from treee_amd import distributed as D
+
+    comm = D.Comm.host()
+    ghosts = quantised_cloud(5000, 91, extent=(20, 6, 20))
+    d_gh = torch.from_numpy(ghosts).cuda()
+    so = T.ShardedOctree(torch.empty((0, 3), dtype=torch.float32, device="cuda"), comm, corner=np.zeros(3, np.float32), size=32.0, top_level=2)
+    tree = T.KDTree.from_shard(so, d_gh)
+    assert len(tree) == 5000
+    dist, index, counts = tree.self_neighbors_dev(31)
+    r_ent, r_cnt = oracle.KDTree(ghosts).k_nearest_batch(ghosts, 31, F32_MAX, threads=8)
+    g = np.zeros((5000, 31), T.ENTRY_DTYPE)
+    g["distance"], g["index"] = dist.cpu().numpy(), index.cpu().numpy().view(np.uint32)
+    check_knn_contract(ghosts, ghosts, g, counts.cpu().numpy(), r_ent, r_cnt)
+    assert int(tree.curvature_dev(31, n_own=0).numel()) == 0
+    tree.close()
+    so.release_local()
+    with pytest.raises(T.TreeeError, match="released"):
+        T.KDTree.from_shard(so, d_gh)
+    so.close()
+    # own points AND ghosts, the copy released after the structure was built: the structure and the octree live on
+    pts = quantised_cloud(40_000, 92, extent=(20, 6, 20))
+    so = T.ShardedOctree(torch.from_numpy(pts).cuda(), comm, top_level=3)
+    tree = T.KDTree.from_shard(so, d_gh[:100])
+    so.release_local()
+    d2, i2, c2 = tree.self_neighbors_dev(8)
+    both = np.concatenate([pts, ghosts[:100]])
+    r_ent, r_cnt = oracle.KDTree(both).k_nearest_batch(both, 8, F32_MAX, threads=8)
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), r_ent["distance"].view(np.uint32))
+    assert so.array("leaf").shape[0] == 40_000
+    tree.close()
+    so.close()
+    comm.close()
 
 
 def test_rccl_transport_with_one_rank(T, oracle):

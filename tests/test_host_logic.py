@@ -424,6 +424,13 @@ def test_bench_starts_its_own_ranks_from_a_bare_python():
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["config"]["comm_ranks"] == 2
     assert d["config"]["owned_points_per_rank"] == [1000, 1001] and "spawned" in d["config"]["launched_by"]
+    # configs[4] across ranks: every rank streams ITS tiles (bench.py --stream-tiles); the plan of a two-rank launch
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--total-points", "1005000000", "--stream-tiles"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sp = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["config"]["stream_tiles"]
+    assert sp["points_per_rank"] == 502_500_000 and sp["tiles_per_rank"] == 34 and sum(sp["tile_points"]) == 502_500_000 and sp["total_points"] == 1_005_000_000
+    assert max(sp["tile_points"]) == 15_000_000 and sp["pinned_host_bytes_per_rank"] == 502_500_000 * 20
     # a rank that fails takes the job down with a non-zero code instead of leaving the other in a collective
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=300,
                        env=dict(env, TREEE_HIP_LIB="/nonexistent/libtreee_hip.so"))

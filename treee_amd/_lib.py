@@ -138,6 +138,7 @@ SYMBOLS = {
     "treee_shard_plan_levels": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(ShardLevels)]),
     "treee_shard_cube_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, C.POINTER(_f32)]),
     "treee_shard_octree_build_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, _f32, _u32, _u32, _u32, _pp]),
+    "treee_shard_octree_release_local": (_i32, [_vp]),
     "treee_shard_octree_info_get": (_i32, [_vp, C.POINTER(ShardPlanInfo), C.POINTER(ShardPlanRank), C.POINTER(ShardLevels)]),
     "treee_shard_exchange_ghosts_dev": (_i32, [_vp, _vp, _vp, _u64, _vp, _u32, _f32, _u64, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "treee_frame_reduce_min_dev": (_i32, [_vp, _vp, _vp, _u64]),

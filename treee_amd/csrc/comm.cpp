@@ -38,7 +38,19 @@ int32_t rccl_api(const RcclApi **out) {
 		const char *names[] = {"librccl.so.1", "librccl.so"};
 		if (const char *env = std::getenv("TREEE_RCCL_LIB")) {
 			h = dlopen(env, RTLD_NOW | RTLD_NOLOAD);
-			if (!h) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+			if (!h) {
+				// the override is taken -- but if the process already holds a librccl (under PyTorch: torch's own), this loads a
+				// SECOND copy with its own transport state, which the paragraph above warns against.  Say so, unless the caller
+				// states that the named file is the tests' stand-in (TREEE_RCCL_LIB_IS_TEST_DOUBLE=1), which brings no RCCL state.
+				void *held = nullptr;
+				for (const char *nm : names)
+					if (!held) held = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
+				if (held && !std::getenv("TREEE_RCCL_LIB_IS_TEST_DOUBLE"))
+					std::fprintf(stderr, "treee: TREEE_RCCL_LIB=%s is loaded beside the librccl this process already holds -- two RCCL copies in one process "
+					                     "(unset it to use the held one)\n", env);
+				if (held) (void)dlclose(held);
+				h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+			}
 			if (!h) return set_err(TREEE_ERR_UNSUPPORTED, "TREEE_RCCL_LIB=%s cannot be opened: %s", env, dlerror());
 		}
 		for (const char *nm : names)

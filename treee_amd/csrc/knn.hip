@@ -502,6 +502,8 @@ template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) {
 	}
 }
 
+// (profiling builds only: duplicates of LDS instructions the compiler must neither merge nor turn into flat accesses)
+[[maybe_unused]] __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; }
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -529,6 +531,13 @@ constexpr int LIST_CAP = TREEE_LIST_CAP; // candidate buckets per wave; more -> 
 #endif
 constexpr int FRONT_CAP = TREEE_FRONT_CAP; // BFS frontier; the default aliases the candidate buffer, which is empty then
 
+// TREEE_AB_DOUBLE (profiles/ab_double.sh; default 0 = the shipped kernel): a bit mask of phases whose work is issued TWICE with the
+// same results -- what a phase costs the kernel is read from what doubling it adds (profiles/README.md, "Round 5").
+//   1 scan: distance arithmetic    2 scan: append's LDS writes    4 scan: broadcast LDS reads    8 flush: sort + merge networks
+//   16 transposed scan: distance + ballot    32 per-lane box tests (find_next, quarters)    64 BFS node tests
+#ifndef TREEE_AB_DOUBLE
+#define TREEE_AB_DOUBLE 0
+#endif
 // DIAG = true compiles the diagnostic counters in (TREEE_KNN_STATS); the shipped instantiation has none
 #define ST(x)                  \
 	do {                       \
@@ -624,7 +633,11 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	// volume is that of 31 neighbours instead of 32.  Exactness is unchanged: candidates pass with `<=`, so the whole tie group of
 	// the k-th distance still arrives, and the entry behind the k-th is still "another point exactly as far, if there is one"
 	// (what out_flags bit 1 reports).
+#ifdef TREEE_NO_KBELOW // (A/B hook: the threshold of rounds 1-4)
+	const bool k_below = false;
+#else
 	const bool k_below = a.k < (uint32_t)SK; // (wave-uniform)
+#endif
 	ST(if (a.thr_io && a.thr_seed && live) thr = a.thr_io[slot]); // diagnostic lower bound: start from the final answer
 	// byte offset of this lane's next free buffer slot (slot stride 256 B); the buffer is appended
 	// to without branches: every candidate is written, the offset only advances if it passed
@@ -646,9 +659,15 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			B[s] = wofs0 + (uint32_t)s * 256u < wofs ? key_make(db, pos) : __longlong_as_double((long long)KEY_MAX);
 		}
 		sort_net<SBUF>(B);
+#if TREEE_AB_DOUBLE & 8
+		sort_net<SBUF>(B); // (a sorted input leaves every network's output unchanged)
+#endif
 #pragma unroll
 		for (int i = SK - SBUF; i < SK; ++i) L[i] = key_min(L[i], B[SK - 1 - i]); // 32 smallest of the union, bitonic
 		bitonic_merge<SK>(L);
+#if TREEE_AB_DOUBLE & 8
+		bitonic_merge<SK>(L);
+#endif
 		{
 			const uint32_t nt = k_below ? key_db(L[SK - 2]) : key_db(L[SK - 1]);
 			thr = nt < thr ? nt : thr;
@@ -699,9 +718,28 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 					db[1] = __float_as_uint(d0.y);
 					db[2] = __float_as_uint(d1.x);
 					db[3] = __float_as_uint(d1.y);
+#if TREEE_AB_DOUBLE & 1
+					v2f qxb = qx2, qyb = qy2, qzb = qz2;
+					asm volatile("" : "+v"(qxb), "+v"(qyb), "+v"(qzb)); // the same query behind an opaque copy: nothing to share with the first evaluation
+					const v2f ex0 = cx0 - qxb, ey0 = cy0 - qyb, ez0 = cz0 - qzb, ex1 = cx1 - qxb, ey1 = cy1 - qyb, ez1 = cz1 - qzb;
+					const v2f e0 = (ex0 * ex0 + ey0 * ey0) + ez0 * ez0, e1 = (ex1 * ex1 + ey1 * ey1) + ez1 * ez1;
+					db[0] = min(db[0], __float_as_uint(e0.x));
+					db[1] = min(db[1], __float_as_uint(e0.y));
+					db[2] = min(db[2], __float_as_uint(e1.x));
+					db[3] = min(db[3], __float_as_uint(e1.y));
+#endif
 				}
 				{
 					const int cn = c0 + SCHUNK < end ? c0 + SCHUNK : c0; // (the last trip re-reads its own candidates: no branch)
+#if TREEE_AB_DOUBLE & 4
+					{
+						v4f tx, ty, tz;
+						asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+						             : "=&v"(tx), "=&v"(ty), "=&v"(tz)
+						             : "v"(lds_addr(&tile[0][cn])), "v"(lds_addr(&tile[1][cn])), "v"(lds_addr(&tile[2][cn]))
+						             : "memory");
+					}
+#endif
 					nx = *(const v4f *)&tile[0][cn];
 					ny = *(const v4f *)&tile[1][cn];
 					nz = *(const v4f *)&tile[2][cn];
@@ -712,6 +750,10 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 					char *w = (char *)buf + wofs;
 					*(uint32_t *)w = base + c0 + j;
 					*(uint32_t *)(w + DB_OFS) = db[j];
+#if TREEE_AB_DOUBLE & 2
+					static_assert(DB_OFS == 16 * 256, "offset1 of the duplicate append");
+					asm volatile("ds_write2st64_b32 %0, %1, %2 offset1:16" ::"v"(lds_addr(w)), "v"(base + c0 + j), "v"(db[j]) : "memory");
+#endif
 					wofs += (db[j] <= thr && act) ? 256u : 0u;
 				}
 			}
@@ -729,6 +771,13 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		const float dy = fmaxf(fmaxf(loy - qy, qy - hiy), 0.0f);
 		const float dz = fmaxf(fmaxf(loz - qz, qz - hiz), 0.0f);
 		const float bd = (dx * dx + dy * dy) + dz * dz;
+#if TREEE_AB_DOUBLE & 32
+		float qxb = qx, qyb = qy, qzb = qz;
+		asm volatile("" : "+v"(qxb), "+v"(qyb), "+v"(qzb));
+		const float ex = fmaxf(fmaxf(lox - qxb, qxb - hix), 0.0f), ey = fmaxf(fmaxf(loy - qyb, qyb - hiy), 0.0f), ez = fmaxf(fmaxf(loz - qzb, qzb - hiz), 0.0f);
+		const float be = (ex * ex + ey * ey) + ez * ez;
+		return __ballot(live && __float_as_uint(bd) <= thr) & __ballot(live && __float_as_uint(be) <= thr);
+#endif
 		return __ballot(live && __float_as_uint(bd) <= thr);
 	};
 
@@ -873,6 +922,21 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 				const float bd = (dx * dx + dy * dy) + dz * dz;
 				hit = hit || (__float_as_uint(bd) <= __float_as_uint(blo.w));
 			}
+#if TREEE_AB_DOUBLE & 64
+			{
+				float lx = lo.x, ly = lo.y, lz = lo.z;
+				asm volatile("" : "+v"(lx), "+v"(ly), "+v"(lz));
+				bool hit2 = false;
+#pragma unroll 2
+				for (int g = 0; g < NG; ++g) {
+					const float4 blo = *(const float4 *)(gbox + g * 8), bhi = *(const float4 *)(gbox + g * 8 + 4);
+					const float dx = fmaxf(fmaxf(lx - bhi.x, blo.x - hi.x), 0.0f), dy = fmaxf(fmaxf(ly - bhi.y, blo.y - hi.y), 0.0f), dz = fmaxf(fmaxf(lz - bhi.z, blo.z - hi.z), 0.0f);
+					const float bd = (dx * dx + dy * dy) + dz * dz;
+					hit2 = hit2 || (__float_as_uint(bd) <= __float_as_uint(blo.w));
+				}
+				hit = hit && hit2;
+			}
+#endif
 			hit = hit && valid;
 			if constexpr (SEG) hit = hit && myseg >= __float_as_uint(lo.w) && myseg <= __float_as_uint(hi.w);
 			// the own bucket's Morton neighbours were scanned above (the own bucket is no seed's descendant)
@@ -1013,7 +1077,15 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 						const float d = (dx * dx + dy * dy) + dz * dz;
 						const uint32_t db = __float_as_uint(d);
 						const bool pass = db <= sthr; // NaN padding never passes
+#if TREEE_AB_DOUBLE & 16
+						float cxb = cand.x, cyb = cand.y, czb = cand.z;
+						asm volatile("" : "+v"(cxb), "+v"(cyb), "+v"(czb));
+						const float sqx2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qx), q ^ 0)), ex = cxb - sqx2, ey = cyb - sqy, ez = czb - sqz;
+						const float e = (ex * ex + ey * ey) + ez * ez;
+						const uint64_t pm = __ballot(pass) & __ballot(__float_as_uint(e) <= sthr);
+#else
 						const uint64_t pm = __ballot(pass);
+#endif
 						if (!pm) continue;
 						const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)wofs, q);
 						const uint32_t room = (uint32_t)SBUF - ((w - (uint32_t)q * 4u) >> 8);
@@ -2212,7 +2284,9 @@ int32_t treee_knn_from_shard_dev(treee_ctx *ctx, const treee_octree *o, const fl
 	*out = nullptr;
 	uint32_t base = 0;
 	std::shared_ptr<SortedCloud> loc = octree_shard_local(o, &base);
-	if (!loc) return set_err(TREEE_ERR_INVALID, "treee_knn_from_shard_dev: not a sharded octree (treee_knn_from_octree_dev serves the others)");
+	if (!loc)
+		return set_err(TREEE_ERR_INVALID, octree_is_shard(o) ? "treee_knn_from_shard_dev: the rank's own sorted copy was released (treee_shard_octree_release_local)"
+		                                                     : "treee_knn_from_shard_dev: not a sharded octree (treee_knn_from_octree_dev serves the others)");
 	const uint64_t n = loc->n, m = n + g;
 	if (m == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");
 	if (m >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "n=%llu exceeds 2^31-1 points per shard", (unsigned long long)m);
@@ -2231,7 +2305,11 @@ int32_t treee_knn_from_shard_dev(treee_ctx *ctx, const treee_octree *o, const fl
 	hipStream_t st = ctx->stream;
 	uint32_t *d_hk = nullptr, *d_pos = nullptr;
 	int32_t rc = ctx->reset();
-	if (rc == TREEE_OK) rc = use_begin(ctx, loc->owner, &loc->sync);
+	bool begun = false; // (a use that has begun is ended on EVERY path: the owner's stream must learn of it -- ADVICE r4)
+	if (rc == TREEE_OK) {
+		rc = use_begin(ctx, loc->owner, &loc->sync);
+		begun = rc == TREEE_OK;
+	}
 	if (rc == TREEE_OK) rc = pool_alloc_t(ctx, m, &fine->d_keys);
 	if (rc == TREEE_OK) rc = pool_alloc_t(ctx, m, &fine->d_perm);
 	if (rc == TREEE_OK) rc = pool_alloc_t(ctx, m, &fine->d_sorted);
@@ -2246,7 +2324,10 @@ int32_t treee_knn_from_shard_dev(treee_ctx *ctx, const treee_octree *o, const fl
 		                   fine->d_perm);
 		if (hipGetLastError() != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_knn_from_shard_dev: gather launch");
 	}
-	if (rc == TREEE_OK) rc = use_end(ctx, loc->owner, &loc->sync);
+	if (begun) {
+		const int32_t e = use_end(ctx, loc->owner, &loc->sync);
+		if (rc == TREEE_OK) rc = e;
+	}
 	if (rc == TREEE_OK) rc = refine_dense_cells(ctx, fine, &t->sc); // (crowded cells only: the cloud is in this structure's order already)
 	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
 	if (rc != TREEE_OK) {

@@ -34,6 +34,7 @@ struct treee_octree {
 	// index_base + input position): what a kNN structure over own + ghost points starts from instead of sorting the tile
 	// again (treee_knn_from_shard_dev).  Null when no point changed hands: `sc` then is that cloud.
 	std::shared_ptr<SortedCloud> sc_local;
+	bool local_released = false; // treee_shard_octree_release_local: the copy above was given back; no kNN structure from this handle any more
 };
 // (the octree's own arrays are only ever touched by its owner's stream and by the caller through
 // treee_octree_dev_ptr, whose ordering is the caller's; the shared sorted cloud carries a HandleSync)
@@ -580,6 +581,7 @@ bool octree_is_shard(const treee_octree *o) { return o && o->shard; }
 std::shared_ptr<SortedCloud> octree_shard_local(const treee_octree *o, uint32_t *index_base) {
 	if (!o || !o->shard) return nullptr;
 	*index_base = (uint32_t)o->sh_rank.index_base;
+	if (o->local_released) return nullptr;
 	return o->sc_local ? o->sc_local : o->sc;
 }
 } // namespace treee
@@ -689,6 +691,14 @@ int32_t treee_sort_build(const float *xyz, uint64_t n, const float corner[3], fl
 	TREEE_HIP(hipMemcpyAsync(d_xyz.p, xyz, n * 12, hipMemcpyHostToDevice, ctx->stream));
 	TREEE_TRY(treee_sort_build_dev(ctx, d_xyz.p, n, corner, size, leaf_cap, lod_cap, out));
 	TREEE_HIP(hipStreamSynchronize(ctx->stream));
+	return TREEE_OK;
+}
+
+int32_t treee_shard_octree_release_local(treee_octree *o) {
+	if (!o) return set_err(TREEE_ERR_INVALID, "treee_shard_octree_release_local: null argument");
+	if (!o->shard) return set_err(TREEE_ERR_INVALID, "treee_shard_octree_release_local: not a sharded octree");
+	o->sc_local.reset(); // (the arrays return to their owner's pool behind the uses its stream knows of: SortedCloud::release)
+	o->local_released = true;
 	return TREEE_OK;
 }
 

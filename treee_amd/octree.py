@@ -106,6 +106,11 @@ class ShardedOctree(Octree):
         _lib.check(_lib.lib().treee_shard_octree_info_get(self._h, C.byref(self.info), C.byref(self.rank_info), C.byref(self.levels)))
         self.n_top_nodes, self.n_top_lod = self.info.n_top_nodes, self.info.n_top_lod
 
+    def release_local(self):
+        """gives back the rank's own Morton-sorted input (kept for KDTree.from_shard; 24 B per point) -- call it once the kNN
+        structure is built (treee_shard_octree_release_local)"""
+        _lib.check(_lib.lib().treee_shard_octree_release_local(self._h))
+
     def piece(self):
         """this rank's arrays and numbering as plain host data (what `assemble` consumes)"""
         lv = self.levels

@@ -145,6 +145,62 @@ class _Staging:
                         self.pinned_read[k].record(self.copy)
 
 
+    def _ingest_into(self, xyz, tiles, ctx):
+        """decodes `tiles` one after the other into the resident buffer `xyz` ([capacity, 3] f32 on the device) on the compute
+        stream, the PCIe copy of tile i + 1 under the decode of tile i.  Returns (points, [points per tile]); nothing is
+        synchronised -- the caller orders its consumers behind self.compute."""
+        torch, lib = self.torch, _lib.lib()
+        capacity = xyz.shape[0]
+        it = self._decoded(iter(tiles))
+        pending = next(it, None)
+        if pending is not None:
+            self._upload(pending, 0, first=True)
+        base, i, sizes = 0, 0, []
+        while pending is not None:
+            tile, slot = pending, i & 1
+            pending = next(it, None)
+            if pending is not None:  # next tile's PCIe copy runs under this tile's decode
+                self._upload(pending, slot ^ 1, first=i == 0)
+            n = tile.n
+            if base + n > capacity:
+                raise ValueError(f"tile {i}: {base + n} points exceed the resident buffer's {capacity}")
+            with torch.cuda.stream(self.compute):
+                self.compute.wait_event(self.copied[slot])
+                _lib.check(lib.treee_decode_las_records_dev(ctx.handle, ptr(self.raw[slot]), n, tile.stride, ptr(tile.scale),
+                                                            ptr(tile.offset), ptr(tile.center), ptr(xyz[base:base + n])))
+                self.consumed[slot].record(self.compute)  # the staging buffer may be overwritten from here on
+            sizes.append(n)
+            base += n
+            i += 1
+        return base, sizes
+
+
+class TileIngest(_Staging):
+    """The ingest half alone: LAS / LAZ tiles from host memory -> one resident xyz buffer on the device (what a rank of the
+    sharded path does with ITS tiles before the sharded step: bench.py --stream-tiles).  `ingest` returns the number of
+    points; the caller's stream must wait for `self.compute` (ingest does that for torch's current stream)."""
+
+    def __init__(self, device, capacity, max_tile_points, max_stride=20):
+        self._init_staging(device, max_tile_points, max_stride)
+        self.ctx = Context(self.device.index, self.compute)
+        self.xyz = self.torch.empty((int(capacity), 3), dtype=self.torch.float32, device=self.device)
+
+    def ingest(self, tiles):
+        n, self.sizes = self._ingest_into(self.xyz, tiles, self.ctx)
+        self.torch.cuda.current_stream(self.device).wait_stream(self.compute)
+        return n
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.shutdown()
+        self.ctx.close()
+
+
+def split_into_las_tiles(xyz, max_tile_points, scale=0.001, stride=20):
+    """a device cloud cut into runs of at most max_tile_points points, each handed over as a pinned LAS tile (las_tile_from_cloud)"""
+    return [las_tile_from_cloud(xyz[a:a + max_tile_points], scale, stride) for a in range(0, xyz.shape[0], max_tile_points)]
+
+
 class TileStream(_Staging):
     """PER TILE, NO GHOST POINTS (module docstring): every tile its own octree and its own neighbourhoods."""
 
@@ -267,29 +323,8 @@ class WholeCloudStream(_Staging):
         torch, lib = self.torch, _lib.lib()
         self._drop()
         ev = {k: torch.cuda.Event(enable_timing=True) for k in ("t0", "ingested", "structure", "knn", "splat")}
-        it = self._decoded(iter(tiles))
-        pending = next(it, None)
-        if pending is not None:
-            self._upload(pending, 0, first=True)
-        base, i, sizes = 0, 0, []
         ev["t0"].record(self.compute)
-        while pending is not None:
-            tile, slot = pending, i & 1
-            pending = next(it, None)
-            if pending is not None:  # next tile's PCIe copy runs under this tile's decode
-                self._upload(pending, slot ^ 1, first=i == 0)
-            n = tile.n
-            if base + n > self.capacity:
-                raise ValueError(f"tile {i}: {base + n} points exceed the stream's capacity of {self.capacity}")
-            with torch.cuda.stream(self.compute):
-                self.compute.wait_event(self.copied[slot])
-                _lib.check(lib.treee_decode_las_records_dev(self.ctx.handle, ptr(self.raw[slot]), n, tile.stride, ptr(tile.scale),
-                                                            ptr(tile.offset), ptr(tile.center), ptr(self.xyz[base:base + n])))
-                self.consumed[slot].record(self.compute)  # the staging buffer may be overwritten from here on
-            sizes.append(n)
-            base += n
-            i += 1
-        total = base
+        total, sizes = self._ingest_into(self.xyz, tiles, self.ctx)
         res = {"points": total, "tiles": sizes, "mode": "one cloud: one cube, one octree, neighbours across tile borders"}
         with torch.cuda.stream(self.compute):
             ev["ingested"].record(self.compute)
