@@ -89,6 +89,7 @@ struct Counters {
 	       tq = 0 /* transposed (query, bucket) pairs */, tq_pass = 0, boxtests = 0 /* per-lane box tests, wave instructions groups */, bfs_batches = 0,
 	       listed = 0, rounds = 0, evals_useful = 0, subtests = 0, lanes_need_sum = 0, full_scans = 0, small_scans = 0, idle_lane_steps = 0, retests = 0,
 	       max_lane_appended = 0, fill_hist[17] = {}, flush_phase[4] = {}, lanes_over8_at_flush = 0, sum_final_thr_ratio = 0,
+	       gq_any = 0, gq_max4 = 0, gq_mean4 = 0, gq_max2 = 0, gq_max8 = 0, gq_buckets = 0,
 	       q_total = 0, q_zero = 0, q_low = 0, q_need_sum = 0, h_total = 0, h_zero = 0, flush_ce = 0, flush_wide = 0, flush_lo_untouched = 0, flush_lo8_untouched = 0, lanes_lo_touched = 0, nbr_need_hist[5] = {}, nbr_total = 0;
 	void add(const Counters &o) {
 		double *a = &waves;
@@ -285,7 +286,45 @@ struct Wave {
 		k.boxtests += 1;
 		return m;
 	}
+	// quarters a wave-shared scan walks today (needed by ANY lane) against what groups of 16 / 32 / 8 Hilbert-adjacent lanes would
+	// walk if every group followed its own list of quarters (the scan then takes as many trips as its busiest group)
+	void group_stats(uint32_t b) {
+		int any = 0, per[8][4] = {};
+		for (int sgm = 0; sgm < 4; ++sgm) {
+			if (b * 64u + (uint32_t)(sgm * 16) >= c.n) continue;
+			bool a = false;
+			for (int l = 0; l < 64; ++l)
+				if (fbits(box_point(c.sub16[(size_t)b * 4 + sgm], q[l])) <= thr[l]) {
+					a = true;
+					per[l / 8][sgm] = 1;
+				}
+			any += a;
+		}
+		auto busiest = [&](int lanes) {
+			int mx = 0;
+			for (int g0 = 0; g0 < 8; g0 += lanes / 8) {
+				int cnt = 0;
+				for (int sgm = 0; sgm < 4; ++sgm) {
+					int need = 0;
+					for (int g = g0; g < g0 + lanes / 8; ++g) need |= per[g][sgm];
+					cnt += need;
+				}
+				mx = std::max(mx, cnt);
+			}
+			return mx;
+		};
+		int sum4 = 0;
+		for (int g0 = 0; g0 < 8; g0 += 2)
+			for (int sgm = 0; sgm < 4; ++sgm) sum4 += per[g0][sgm] | per[g0 + 1][sgm];
+		k.gq_any += any;
+		k.gq_max4 += busiest(16);
+		k.gq_max2 += busiest(32);
+		k.gq_max8 += busiest(8);
+		k.gq_mean4 += sum4 / 4.0;
+		k.gq_buckets += 1;
+	}
 	void quarter_stats(uint32_t b) {
+		group_stats(b);
 		for (int sgm = 0; sgm < 4; ++sgm) {
 			if (b * 64u + (uint32_t)(sgm * 16) >= c.n) continue;
 			int need = 0;
@@ -519,7 +558,9 @@ int main(int argc, char **argv) {
 	    {"pl sub32 C=all nbr0/4 lazy", 1, 32, 100000, 0, 4, 1, 0},
 	};
 	printf("%-30s %7s %7s %7s %7s %7s %7s %7s %7s %7s %7s %7s | %8s\n", "variant", "bkts", "listed", "steps", "flush", "append", "tq", "boxt", "subt", "rounds", "retest", "idle%", "VALU~");
+	const bool only_first = getenv("SIM_ONLY_CUR") != nullptr;
 	for (const Variant &v : vs) {
+		if (only_first && &v != &vs[0]) break;
 		Counters total;
 #pragma omp parallel
 		{
@@ -558,6 +599,9 @@ int main(int argc, char **argv) {
 		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF && v.tighten == 0)
 			printf("   neighbour buckets by needing lanes: none %.1f%%, 1-11 %.1f%%, 12-23 %.1f%%, 24-47 %.1f%%, 48-64 %.1f%%\n", 100 * total.nbr_need_hist[0] / total.nbr_total,
 			       100 * total.nbr_need_hist[1] / total.nbr_total, 100 * total.nbr_need_hist[2] / total.nbr_total, 100 * total.nbr_need_hist[3] / total.nbr_total, 100 * total.nbr_need_hist[4] / total.nbr_total);
+		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF && v.tighten == 0)
+			printf("   quarters walked per wave-shared bucket: any lane %.2f | busiest of 2 groups of 32 lanes %.2f | of 4 groups of 16 %.2f (mean group %.2f) | of 8 groups of 8 %.2f | buckets per wave %.2f\n",
+			       total.gq_any / total.gq_buckets, total.gq_max2 / total.gq_buckets, total.gq_max4 / total.gq_buckets, total.gq_mean4 / total.gq_buckets, total.gq_max8 / total.gq_buckets, total.gq_buckets / W);
 		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF) {
 			printf("   max-lane appended per wave %.1f | flushes by phase own %.2f nbr %.2f list %.2f | lanes with > 8 pending at a flush %.2f | fill histogram:", total.max_lane_appended / W,
 			       total.flush_phase[0] / W, total.flush_phase[1] / W, total.flush_phase[2] / W, total.lanes_over8_at_flush / total.flushes);

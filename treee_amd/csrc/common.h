@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <unordered_map>
 #include <vector>
 
@@ -382,6 +383,26 @@ std::recursive_mutex &default_ctx_mutex();
 #define TREEE_DEFAULT_CTX(ctx)                                                     \
 	std::lock_guard<std::recursive_mutex> default_ctx_lock__(default_ctx_mutex()); \
 	TREEE_TRY(default_ctx(&ctx))
+
+// Host scratch whose size depends on the caller's arguments, inside extern "C" bodies: nothing may unwind across the C ABI, so
+// no std::vector there (its allocation throws) -- a failed allocation is a status like any other.
+template <class T> struct HostBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	HostBuf() = default;
+	HostBuf(const HostBuf &) = delete;
+	HostBuf &operator=(const HostBuf &) = delete;
+	~HostBuf() { delete[] p; }
+	int32_t alloc(size_t count) {
+		p = new (std::nothrow) T[count ? count : 1]();
+		if (!p) return set_err(TREEE_ERR_NOMEM, "host scratch of %zu bytes", count * sizeof(T));
+		n = count;
+		return TREEE_OK;
+	}
+	T *data() { return p; }
+	size_t size() const { return n; }
+	T &operator[](size_t i) { return p[i]; }
+};
 
 template <class T> struct DevBuf { // RAII for hipMalloc'd temporaries in host wrappers
 	T *p = nullptr;

@@ -2409,7 +2409,8 @@ int32_t treee_curvature_ties_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k,
 }
 
 int32_t treee_curvature_own_dev(treee_ctx *ctx, const treee_knn *t, uint64_t n_own, uint32_t k, float max_dist_sq, float *d_curve) {
-	if (!ctx || !t || !d_curve) return set_err(TREEE_ERR_INVALID, "treee_curvature_own_dev: null argument");
+	if (!ctx || !t || (n_own && !d_curve)) return set_err(TREEE_ERR_INVALID, "treee_curvature_own_dev: null argument");
+	if (n_own == 0) return TREEE_OK; // (a rank that owns nothing: its ghosts are neighbours of nobody here)
 	TREEE_HIP(hipSetDevice(ctx->device));
 	TREEE_TRY(ctx->reset());
 	return launch_knn(ctx, t, nullptr, t->sc->n, k, max_dist_sq, nullptr, nullptr, nullptr, d_curve, n_own);
@@ -2464,7 +2465,8 @@ int32_t treee_knn_empty(const treee_knn *t, const float *q, uint64_t nq, float m
 	if (!t || (nq && (!q || !empty_out))) return set_err(TREEE_ERR_INVALID, "treee_knn_empty: null argument");
 	if (nq == 0) return TREEE_OK;
 	// EmptySet (best_set.rs:111-131): empty <=> no point with distance < max  <=> k=1 query finds nothing
-	std::vector<uint32_t> counts(nq);
+	HostBuf<uint32_t> counts;
+	TREEE_TRY(counts.alloc(nq));
 	TREEE_TRY(treee_knn_query_batch(t, q, nq, 1, max_dist_sq, nullptr, counts.data()));
 	for (uint64_t i = 0; i < nq; ++i) empty_out[i] = counts[i] == 0 ? 1 : 0;
 	return TREEE_OK;

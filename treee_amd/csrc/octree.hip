@@ -365,7 +365,8 @@ int32_t shard_cube(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64_
 		float *d_partial = nullptr;
 		uint32_t grid = 0;
 		TREEE_TRY(bbox_partials_dev(ctx, d_xyz, n, &d_partial, &grid));
-		std::vector<float> h((size_t)grid * 6);
+		HostBuf<float> h;
+		TREEE_TRY(h.alloc((size_t)grid * 6));
 		TREEE_HIP(hipMemcpyAsync(h.data(), d_partial, h.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
 		TREEE_HIP(hipStreamSynchronize(ctx->stream));
 		for (uint32_t b = 0; b < grid; ++b)
@@ -374,7 +375,8 @@ int32_t shard_cube(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64_
 				mine[3 + a] = fmaxf(mine[3 + a], h[b * 6 + 3 + a]);
 			}
 	}
-	std::vector<float> all((size_t)comm->world * 6);
+	HostBuf<float> all;
+	TREEE_TRY(all.alloc((size_t)comm->world * 6));
 	TREEE_TRY(comm->all_gather_host(ctx, mine, all.data(), sizeof(mine)));
 	float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, size = 0.0f;
 	for (int r = 0; r < comm->world; ++r)

@@ -185,7 +185,8 @@ int32_t bbox_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, float corner_ou
 	TREEE_TRY(ctx->alloc_t(grid * 6, &d_partial));
 	hipLaunchKernelGGL(k_bbox_partial, dim3(grid), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, d_partial);
 	TREEE_LAUNCH_CHECK();
-	std::vector<float> h(grid * 6);
+	HostBuf<float> h;
+	TREEE_TRY(h.alloc((size_t)grid * 6));
 	TREEE_HIP(hipMemcpyAsync(h.data(), d_partial, grid * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	TREEE_HIP(hipStreamSynchronize(ctx->stream));
 	float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};

@@ -164,7 +164,8 @@ int32_t treee_shard_exchange_ghosts_dev(treee_ctx *ctx, treee_comm *comm, float 
 	TREEE_HIP(hipMemsetAsync(d_recv + (uint64_t)rank * block, 0xFF, block * 4, st)); // own block: not a ghost of oneself
 	const Box2 dilated = {x0 - halo, x1 + halo, z0 - halo, z1 + halo}, none = {0.0f, 0.0f, 0.0f, 0.0f};
 	TREEE_TRY(select_xz(ctx, d_recv, block / 3 * (uint64_t)world, dilated, none, d_cloud + 3ull * n_own, ghost_cap, d_cnt + 1));
-	std::vector<uint32_t> h((size_t)world + 1);
+	HostBuf<uint32_t> h;
+	TREEE_TRY(h.alloc((size_t)world + 1));
 	TREEE_HIP(hipMemcpyAsync(h.data(), d_cnt + 1, 4, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipMemcpyAsync(h.data() + 1, d_heads, (size_t)world * 4, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipStreamSynchronize(st));
