@@ -2682,6 +2682,18 @@ def test_segments_calculate_fuzz_vs_oracle(T, oracle, seed):
     _check_segments_against_oracle(T, oracle, pts[perm], seg[perm], S, device=bool(seed & 1))
 
 
+@pytest.mark.parametrize("seed", range(1000, 1010))
+def test_calculations_soak_subset_in_the_suite(T, oracle, seed):
+    """the hull kernel's drops (coarse-polygon and residue filters) are sound only while hulls grow and every edge
+    has a unit normal -- conditions enforced by detectors, one of which the hand-run soak found missing (seed 531).  A bounded
+    part of that soak (tests/soak_calculations_seeds.py: the three seeded generators -- long slices of discs, rings past both
+    hull capacities, lattices, bands, near-lines, far-off and non-finite coordinates; whole fuzzed clouds; planted points at
+    infinity) therefore runs with the suite, on seeds no committed test uses."""
+    test_long_slices_fuzz_vs_oracle(T, oracle, seed)
+    test_segments_calculate_fuzz_vs_oracle(T, oracle, seed)
+    test_long_slices_with_points_at_infinity(T, oracle, seed)
+
+
 def test_deferred_octree_on_a_second_stream(T, oracle):
     """treee_sort_dev + treee_octree_complete_dev: the node table built later, on a context of another stream while a kNN
     kernel over the same sorted cloud runs on the first, is bit for bit the one-call build; the kNN structure taken from
