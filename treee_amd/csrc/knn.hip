@@ -502,10 +502,18 @@ template <int N> __device__ __forceinline__ void bitonic_merge(double (&v)[N]) {
 	}
 }
 
-// (profiling builds only: duplicates of LDS instructions the compiler must neither merge nor turn into flat accesses)
-[[maybe_unused]] __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; }
+// the LDS byte address of an object in shared memory, for hand-written ds_ instructions
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; }
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+// a - b on both halves in ONE instruction.  Written by hand because hipcc packs only one of the scan loop's two candidate
+// pairs by itself: for the other it emitted six v_sub_f32 against six further copies of the query (three instructions of a
+// trip's 38 and six VGPRs; round 5).  Same IEEE subtraction either way.
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b) {
+	v2f r;
+	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
 
 #ifndef TREEE_SCAN_PIPE
 #define TREEE_SCAN_PIPE 1
@@ -643,6 +651,8 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	// to without branches: every candidate is written, the offset only advances if it passed
 	const uint32_t wofs0 = (uint32_t)lane * 4u;
 	uint32_t wofs = wofs0;
+	uint32_t wlim = wofs0 + (uint32_t)(SBUF - SCHUNK) * 256u; // a buffer with fewer than SCHUNK free slots is flushed before the next trip
+	asm volatile("" : "+v"(wlim)); // (kept in its own register: one compare per trip instead of a subtraction and a compare)
 	constexpr uint32_t DB_OFS = SBUF * 64 * 4; // distance-bits plane behind the position plane
 	uint32_t st_buckets = 0, st_flush = 0, st_nodes = 0, st_need = 0, st_small = 0;
 	unsigned long long st_t0 = 0ull, st_tp = 0ull, st_tf = 0ull;
@@ -653,10 +663,40 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	auto flush = [&]() __attribute__((always_inline)) {
 		ST(st_tf = __builtin_amdgcn_s_memtime());
 		double B[SBUF];
+		// slots at or behind the lane's fill count carry a key above every real one: distance bits 0x7FEFFFFF (the high word of
+		// KEY_MAX) over whatever position the slot last held -- such a key never wins a minimum against a list entry, so its low
+		// word is never looked at.  (Round 5: one compare against an immediate and one select per slot; comparing the slot's
+		// ADDRESS with the write offset kept sixteen per-lane addresses alive in VGPRs through the whole kernel.)
+		const uint32_t fill = (wofs - wofs0) >> 8;
+		if constexpr (SBUF == 16 && KEY_BIAS == 0u) {
+			// every slot as ONE register pair (position, distance bits) = the key itself: ds_read2st64_b32 with the two planes as its
+			// two offsets.  Left to itself hipcc pairs two POSITIONS per read and assembles the keys with a v_mov per slot.
+			const uint32_t ba = lds_addr(&buf[lane]);
+			asm volatile("ds_read2st64_b32 %0, %16 offset0:0 offset1:16\n\tds_read2st64_b32 %1, %16 offset0:1 offset1:17\n\t"
+			             "ds_read2st64_b32 %2, %16 offset0:2 offset1:18\n\tds_read2st64_b32 %3, %16 offset0:3 offset1:19\n\t"
+			             "ds_read2st64_b32 %4, %16 offset0:4 offset1:20\n\tds_read2st64_b32 %5, %16 offset0:5 offset1:21\n\t"
+			             "ds_read2st64_b32 %6, %16 offset0:6 offset1:22\n\tds_read2st64_b32 %7, %16 offset0:7 offset1:23\n\t"
+			             "ds_read2st64_b32 %8, %16 offset0:8 offset1:24\n\tds_read2st64_b32 %9, %16 offset0:9 offset1:25\n\t"
+			             "ds_read2st64_b32 %10, %16 offset0:10 offset1:26\n\tds_read2st64_b32 %11, %16 offset0:11 offset1:27\n\t"
+			             "ds_read2st64_b32 %12, %16 offset0:12 offset1:28\n\tds_read2st64_b32 %13, %16 offset0:13 offset1:29\n\t"
+			             "ds_read2st64_b32 %14, %16 offset0:14 offset1:30\n\tds_read2st64_b32 %15, %16 offset0:15 offset1:31\n\t"
+			             "s_waitcnt lgkmcnt(0)"
+			             : "=&v"(B[0]), "=&v"(B[1]), "=&v"(B[2]), "=&v"(B[3]), "=&v"(B[4]), "=&v"(B[5]), "=&v"(B[6]), "=&v"(B[7]), "=&v"(B[8]), "=&v"(B[9]),
+			               "=&v"(B[10]), "=&v"(B[11]), "=&v"(B[12]), "=&v"(B[13]), "=&v"(B[14]), "=&v"(B[15])
+			             : "v"(ba)
+			             : "memory");
 #pragma unroll
-		for (int s = 0; s < SBUF; ++s) {
-			const uint32_t pos = buf[s * 64 + lane], db = buf[SBUF * 64 + s * 64 + lane];
-			B[s] = wofs0 + (uint32_t)s * 256u < wofs ? key_make(db, pos) : __longlong_as_double((long long)KEY_MAX);
+			for (int s = 0; s < SBUF; ++s) {
+				const unsigned long long kk = (unsigned long long)__double_as_longlong(B[s]);
+				const uint32_t hi = (uint32_t)s < fill ? (uint32_t)(kk >> 32) : (uint32_t)(KEY_MAX >> 32);
+				B[s] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (uint32_t)kk));
+			}
+		} else {
+#pragma unroll
+			for (int s = 0; s < SBUF; ++s) {
+				const uint32_t pos = buf[s * 64 + lane], db = buf[SBUF * 64 + s * 64 + lane];
+				B[s] = key_make((uint32_t)s < fill ? db : (uint32_t)(KEY_MAX >> 32) - KEY_BIAS, pos);
+			}
 		}
 		sort_net<SBUF>(B);
 #if TREEE_AB_DOUBLE & 8
@@ -708,11 +748,11 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			v4f nx = *(const v4f *)&tile[0][begin], ny = *(const v4f *)&tile[1][begin], nz = *(const v4f *)&tile[2][begin];
 #pragma unroll 1
 			for (int c0 = begin; c0 < end; c0 += SCHUNK) {
-				if (__any(wofs - wofs0 > (uint32_t)(SBUF - SCHUNK) * 256u)) flush();
+				if (__any(wofs > wlim)) flush();
 				uint32_t db[SCHUNK];
 				{
 					const v2f cx0 = {nx.x, nx.y}, cx1 = {nx.z, nx.w}, cy0 = {ny.x, ny.y}, cy1 = {ny.z, ny.w}, cz0 = {nz.x, nz.y}, cz1 = {nz.z, nz.w};
-					const v2f dx0 = cx0 - qx2, dy0 = cy0 - qy2, dz0 = cz0 - qz2, dx1 = cx1 - qx2, dy1 = cy1 - qy2, dz1 = cz1 - qz2;
+					const v2f dx0 = pk_sub(cx0, qx2), dy0 = pk_sub(cy0, qy2), dz0 = pk_sub(cz0, qz2), dx1 = pk_sub(cx1, qx2), dy1 = pk_sub(cy1, qy2), dz1 = pk_sub(cz1, qz2);
 					const v2f d0 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0, d1 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1; // metric.rs:21-26
 					db[0] = __float_as_uint(d0.x);
 					db[1] = __float_as_uint(d0.y);
@@ -1160,19 +1200,26 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 
 	PH(5);
 	const uint32_t k = a.k;
+	// valid entries among the first k: the list is ascending and an unused entry carries max_distance, so the valid ones lead --
+	// count = min(k, valid entries of the whole list).  (Written as `s < k && valid` per entry, the 32 wave-uniform conditions
+	// were hoisted into 32 SGPR pairs that spilled to VGPR lanes: ~250 v_writelane / v_readlane per wave; round 5.)
 	uint32_t count = 0;
 #pragma unroll
-	for (int s = 0; s < SK; ++s) count += ((uint32_t)s < k && key_db(L[s]) < a.maxbits) ? 1u : 0u;
+	for (int s = 0; s < SK; ++s) count += key_db(L[s]) < a.maxbits ? 1u : 0u;
+	count = count < k ? count : k;
 	if (a.out_count) a.out_count[row] = count;
 	if (a.out_flags) { // (wave-uniform) rows whose list the reference's KD-tree may order or cut differently: k-nearest/src/kd_tree.rs:114,125 decide
 		// equal distances by visit order, this structure by (distance, cell, index) -- SURVEY.md H2
-		uint32_t f = 0u;
+		uint32_t m = 0u; // bit s: entries s and s + 1 are equally far (and both exist)
 #pragma unroll
-		for (int s = 0; s + 1 < SK; ++s) {
-			const bool eq = key_db(L[s]) == key_db(L[s + 1]) && key_db(L[s + 1]) < a.maxbits;
-			f |= (eq && (uint32_t)(s + 1) < k) ? 1u : 0u;  // both inside the k
-			f |= (eq && (uint32_t)(s + 1) == k) ? 2u : 0u; // the k-th and the entry behind it
+		for (int s = 0; s + 1 < SK && s < 32; ++s) m |= (key_db(L[s]) == key_db(L[s + 1]) && key_db(L[s + 1]) < a.maxbits) ? 1u << s : 0u;
+		uint32_t m_hi = 0u; // (the 64-entry list: bits 32 ...)
+		if constexpr (SK > 33) {
+#pragma unroll
+			for (int s = 32; s + 1 < SK; ++s) m_hi |= (key_db(L[s]) == key_db(L[s + 1]) && key_db(L[s + 1]) < a.maxbits) ? 1u << (s - 32) : 0u;
 		}
+		const unsigned long long mm = ((unsigned long long)m_hi << 32) | m, inside = k >= 2u ? (1ull << (k - 1u)) - 1ull : 0ull; // pairs (s, s + 1) with s + 1 < k
+		const uint32_t f = ((mm & inside) ? 1u : 0u) | ((k < (uint32_t)SK && ((mm >> (k - 1u)) & 1ull)) ? 2u : 0u); // ... and the pair (k - 1, k)
 		a.out_flags[row] = (uint8_t)f;
 	}
 	if (a.out_dist || a.out_index) {
@@ -1192,7 +1239,10 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		const float len = (float)count;
 		float mean[3] = {0.0f, 0.0f, 0.0f};
 		float var[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-		if constexpr (SKT > 32) { // (64 x 3 coordinates do not fit beside the list: two gathers)
+		// GENERAL form: two gathers, a lane sums its first `count` entries (one per-lane compare per entry; an unused entry names
+		// position 0, a valid address, and is never summed).  It serves the 64-entry list (64 x 3 coordinates do not fit beside the
+		// list) and the waves in which some lane holds fewer than k neighbours (a bounded radius, a tiny cloud).
+		auto general = [&]() __attribute__((always_inline)) {
 #pragma unroll
 			for (int s = 0; s < SK; ++s) {
 				if ((uint32_t)s < count) {
@@ -1216,45 +1266,44 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 						for (int y = 0; y < 3; ++y) var[x][y] += df[x] * df[y];
 				}
 			}
+		};
+		if constexpr (SKT > 32) {
+			general();
 		} else {
-		float nx[SK], ny[SK], nz[SK];
+			// FAST form (round 5): the reference's k (31 in the 32-entry list; a full 16-entry list) with every lane of the wave holding
+			// k neighbours -- nearly every wave under the unbounded radius: the coordinates gathered once, straight-line code over a
+			// compile-time number of entries, no condition anywhere.  (Written with wave-uniform `s < k` conditions per entry, the 32
+			// of them were hoisted into SGPR pairs that spilled to VGPR lanes: ~250 v_writelane / v_readlane per wave.)
+			constexpr int FASTK = SK == 32 ? 31 : SK;
+			if (k == (uint32_t)FASTK && __all(count == k)) {
+				float nx[FASTK], ny[FASTK], nz[FASTK];
 #pragma unroll
-		for (int s = 0; s < SK; ++s) {
-			if ((uint32_t)s < k) { // (wave-uniform)
-				const float4 p = a.pts[key_pos(L[s])];
-				nx[s] = p.x;
-				ny[s] = p.y;
-				nz[s] = p.z;
-			}
-		}
-		const bool all_full = __all(count == k);
-		auto sums = [&](auto full) __attribute__((always_inline)) {
+				for (int s = 0; s < FASTK; ++s) {
+					const float4 p = a.pts[key_pos(L[s])];
+					nx[s] = p.x;
+					ny[s] = p.y;
+					nz[s] = p.z;
+				}
 #pragma unroll
-			for (int s = 0; s < SK; ++s) {
-				if ((uint32_t)s < k && (decltype(full)::value || (uint32_t)s < count)) {
+				for (int s = 0; s < FASTK; ++s) {
 					mean[0] += nx[s];
 					mean[1] += ny[s];
 					mean[2] += nz[s];
 				}
-			}
-			mean[0] = mean[0] / len;
-			mean[1] = mean[1] / len;
-			mean[2] = mean[2] / len;
+				mean[0] = mean[0] / len;
+				mean[1] = mean[1] / len;
+				mean[2] = mean[2] / len;
 #pragma unroll
-			for (int s = 0; s < SK; ++s) {
-				if ((uint32_t)s < k && (decltype(full)::value || (uint32_t)s < count)) {
+				for (int s = 0; s < FASTK; ++s) {
 					const float df[3] = {nx[s] - mean[0], ny[s] - mean[1], nz[s] - mean[2]};
 #pragma unroll
 					for (int x = 0; x < 3; ++x)
 #pragma unroll
 						for (int y = 0; y < 3; ++y) var[x][y] += df[x] * df[y];
 				}
+			} else {
+				general();
 			}
-		};
-		if (all_full)
-			sums(std::true_type{});
-		else
-			sums(std::false_type{});
 		}
 #pragma unroll
 		for (int x = 0; x < 3; ++x)
@@ -1453,8 +1502,8 @@ int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint
 	return TREEE_OK;
 }
 
-// dispatch key of a bucket: (XCD label of its Morton range) << 8 | size class, where the size class is
-// 255 - exponent byte of its squared box diagonal (small key = large box) and ranges of ORDER_RANGE buckets
+// dispatch key of a bucket: (XCD label of its Morton range) << 5 | size class, where the size class falls with the
+// exponent byte of its squared box diagonal (small key = large box) and ranges of ORDER_RANGE buckets
 // are dealt to the 8 XCD labels in turn
 constexpr uint32_t ORDER_RANGE = TREEE_ORDER_RANGE;
 __global__ __launch_bounds__(256) void k_bucket_class(const float4 *__restrict__ bvh, uint32_t nb, uint32_t P, uint32_t *__restrict__ key) {
@@ -1463,8 +1512,12 @@ __global__ __launch_bounds__(256) void k_bucket_class(const float4 *__restrict__
 	const float4 lo = bvh[2ull * (P + b) + 0], hi = bvh[2ull * (P + b) + 1];
 	const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
 	const float d2 = dx * dx + dy * dy + dz * dz;
+	// five bits of size class: the exponent byte of the squared diagonal, clamped to [111, 142] (diagonals from 4 mm to 180 m; what
+	// lies outside shares the end classes) -- with the three label bits an 8-bit key, ONE radix pass over the buckets (round 5;
+	// the 11-bit key of rounds 1-4 took two).  Only the dispatch order depends on it, never a result.
 	const uint32_t e = (d2 == d2 && d2 > 0.0f) ? ((__float_as_uint(d2) >> 23) & 255u) : 0u;
-	key[b] = (((b / ORDER_RANGE) & 7u) << 8) | (255u - e);
+	const uint32_t c = e < 111u ? 0u : (e > 142u ? 31u : e - 111u);
+	key[b] = (((b / ORDER_RANGE) & 7u) << 5) | (31u - c);
 }
 
 // number of buckets with XCD label x, and of those with a smaller label
@@ -2038,13 +2091,15 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t, const uint32_t *d_bucket_seg = n
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->P * 2 * 2, &t->d_bvh));
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->nb * 8, &t->d_sub));
 	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 16)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, d_bucket_seg, t->d_bvh, t->d_sub);
+	TREEE_LAUNCH_CHECK();
 	uint32_t lvl = t->P >> 1;
 	for (; lvl > INNER_TOP; lvl >>= 1) // nodes [lvl, 2*lvl)
 		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
 	if (lvl >= 1) hipLaunchKernelGGL(k_inner_aabb_top, dim3(1), dim3(INNER_TOP), 0, ctx->stream, t->d_bvh, lvl); // the levels that fit one workgroup
 	TREEE_LAUNCH_CHECK();
-	// dispatch table of the self-query kernel: a stable radix sort of the buckets by (XCD label, size class),
-	// then the 8 label segments interleaved
+	// dispatch table of the self-query kernel: a stable radix sort of the buckets by (XCD label, size class) -- an 8-bit key,
+	// one pass --, then the 8 label segments interleaved.  (On the context's auxiliary stream beside the inner levels it was
+	// measured 15 us SLOWER per 15 M-point build than behind them: the fork / join events cost more than the two short chains overlap.)
 	uint32_t *d_key = nullptr, *d_key_sorted = nullptr, *d_sorted = nullptr;
 	uint32_t longest = 0;
 	for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, order_count(t->nb, x));
@@ -2055,7 +2110,7 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t, const uint32_t *d_bucket_seg = n
 	TREEE_TRY(pool_alloc_t(ctx, t->n_order, &t->d_order));
 	hipLaunchKernelGGL(k_bucket_class, dim3(div_up(t->nb, 256)), dim3(256), 0, ctx->stream, t->d_bvh, t->nb, t->P, d_key);
 	TREEE_LAUNCH_CHECK();
-	TREEE_TRY(sort_pairs_dev(ctx, d_key, nullptr, t->nb, 11, d_key_sorted, d_sorted));
+	TREEE_TRY(sort_pairs_dev(ctx, d_key, nullptr, t->nb, 8, d_key_sorted, d_sorted));
 	hipLaunchKernelGGL(k_order_interleave, dim3(div_up(t->n_order, 256)), dim3(256), 0, ctx->stream, d_sorted, t->nb, t->n_order, t->d_order);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;

@@ -246,6 +246,34 @@ __global__ __launch_bounds__(RS_BLOCK) void rs_hist(const uint32_t *__restrict__
 	table[(uint32_t)tid * ntiles + blockIdx.x] = sum;
 }
 
+// Morton keys of one radix tile AND the tile's histogram of the first digit (round 5: the first pass's rs_hist re-read the 4 B
+// per point this kernel had just written -- 60 MB and a launch per 15 M points).  cube: (corner.xyz, size) on the device.
+__global__ __launch_bounds__(RS_BLOCK) void k_morton_keys_hist(const float *__restrict__ xyz, uint32_t n, const float *__restrict__ cube, uint32_t *__restrict__ keys,
+                                                               uint32_t *__restrict__ table, uint32_t ntiles) {
+	constexpr int SETS = TREEE_RS_HSETS;
+	__shared__ uint32_t h[SETS][256];
+	const int tid = threadIdx.x, w = tid / (256 / SETS);
+#pragma unroll
+	for (int i = 0; i < SETS; ++i) h[i][tid] = 0;
+	__syncthreads();
+	const float cx = cube[0], cy = cube[1], cz = cube[2], size = cube[3];
+	const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll 4
+	for (int i = 0; i < RS_ITEMS; ++i) {
+		const uint32_t idx = base + i * RS_BLOCK + tid;
+		if (idx < n) {
+			const uint32_t k = morton30(xyz[3ull * idx + 0], xyz[3ull * idx + 1], xyz[3ull * idx + 2], cx, cy, cz, size);
+			keys[idx] = k;
+			atomicAdd(&h[w][k & 255u], 1u);
+		}
+	}
+	__syncthreads();
+	uint32_t sum = 0;
+#pragma unroll
+	for (int i = 0; i < SETS; ++i) sum += h[i][tid];
+	table[(uint32_t)tid * ntiles + blockIdx.x] = sum;
+}
+
 __global__ __launch_bounds__(256) void rs_scan_rows(uint32_t *__restrict__ table, uint32_t ntiles,
                                                      uint32_t *__restrict__ totals) {
 	__shared__ uint32_t part[4];
@@ -359,8 +387,19 @@ __global__ __launch_bounds__(256) void k_iota_copy(const uint32_t *__restrict__ 
 	vals_out[i] = vals_in ? vals_in[i] : i;
 }
 
+static int32_t sort_pairs_impl(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in, uint64_t n64, int bits, uint32_t *d_keys_out,
+                               uint32_t *d_vals_out, const float *d_xyz_for_keys, const float *d_cube_for_keys);
 int32_t sort_pairs_dev(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in,
                        uint64_t n64, int bits, uint32_t *d_keys_out, uint32_t *d_vals_out) {
+	return sort_pairs_impl(ctx, d_keys_in, d_vals_in, n64, bits, d_keys_out, d_vals_out, nullptr, nullptr);
+}
+// 30-bit Morton keys of a cloud generated INTO d_keys_scratch and sorted with their indices: the key kernel leaves the first
+// pass's histogram behind (k_morton_keys_hist)
+int32_t morton_sort_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *d_cube, uint32_t *d_keys_scratch, uint32_t *d_keys_out, uint32_t *d_perm_out) {
+	return sort_pairs_impl(ctx, d_keys_scratch, nullptr, n, 30, d_keys_out, d_perm_out, d_xyz, d_cube);
+}
+static int32_t sort_pairs_impl(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in, uint64_t n64, int bits, uint32_t *d_keys_out,
+                               uint32_t *d_vals_out, const float *d_xyz_for_keys, const float *d_cube_for_keys) {
 	if (n64 == 0) return TREEE_OK;
 	if (n64 >= (1ull << 31)) return set_err(TREEE_ERR_UNSUPPORTED, "sort: n=%llu exceeds 2^31-1 per shard", (unsigned long long)n64);
 	const uint32_t n = (uint32_t)n64;
@@ -387,7 +426,10 @@ int32_t sort_pairs_dev(treee_ctx *ctx, const uint32_t *d_keys_in, const uint32_t
 		uint32_t *kout = to_out ? d_keys_out : d_ktmp;
 		uint32_t *vout = to_out ? d_vals_out : d_vtmp;
 		const int shift = 8 * p;
-		hipLaunchKernelGGL(rs_hist, dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, kin, n, shift, d_table, ntiles);
+		if (p == 0 && d_xyz_for_keys) // keys generated here, with the first digit's histogram
+			hipLaunchKernelGGL(k_morton_keys_hist, dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, d_xyz_for_keys, n, d_cube_for_keys, (uint32_t *)kin, d_table, ntiles);
+		else
+			hipLaunchKernelGGL(rs_hist, dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, kin, n, shift, d_table, ntiles);
 		hipLaunchKernelGGL(rs_scan_rows, dim3(256), dim3(256), 0, ctx->stream, d_table, ntiles, d_totals);
 		hipLaunchKernelGGL(rs_scatter, dim3(ntiles), dim3(RS_BLOCK), 0, ctx->stream, kin, vin, kout, vout, n, shift, d_table, d_totals, ntiles);
 		TREEE_LAUNCH_CHECK();
@@ -576,17 +618,22 @@ int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const
 	TREEE_TRY(pool_alloc_t(ctx, cnt, &sc->d_sorted));
 	uint32_t *d_keys_raw = nullptr;
 	TREEE_TRY(ctx->alloc_t(cnt, &d_keys_raw));
-	if (sc->cube_pending) {
-		if (n) hipLaunchKernelGGL(k_morton_keys_cube, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, sc->d_cube, d_keys_raw);
-		TREEE_LAUNCH_CHECK();
+	if (sc->cube_pending && !hilbert_order && n) {
+		// (the common path -- cube from the data, Morton order: keys and the first radix histogram from one kernel)
+		TREEE_TRY(morton_sort_dev(ctx, d_xyz, n, sc->d_cube, d_keys_raw, sc->d_keys, sc->d_perm));
 	} else {
-		TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
+		if (sc->cube_pending) {
+			if (n) hipLaunchKernelGGL(k_morton_keys_cube, dim3(div_up(n, 256)), dim3(256), 0, ctx->stream, d_xyz, (uint32_t)n, sc->d_cube, d_keys_raw);
+			TREEE_LAUNCH_CHECK();
+		} else {
+			TREEE_TRY(morton_keys_dev(ctx, d_xyz, n, sc->corner, sc->size, d_keys_raw));
+		}
+		if (hilbert_order) {
+			TREEE_TRY(hilbert_keys_dev(ctx, d_keys_raw, nullptr, n, d_keys_raw));
+			sc->hilbert = true;
+		}
+		TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, sc->d_keys, sc->d_perm));
 	}
-	if (hilbert_order) {
-		TREEE_TRY(hilbert_keys_dev(ctx, d_keys_raw, nullptr, n, d_keys_raw));
-		sc->hilbert = true;
-	}
-	TREEE_TRY(sort_pairs_dev(ctx, d_keys_raw, nullptr, n, 30, sc->d_keys, sc->d_perm));
 	// keys and permutation are final here: work that needs nothing else (the octree levels) may start on the context's
 	// auxiliary stream while this one gathers the records
 	if (fork_after_sort) TREEE_TRY(ctx->fork());
