@@ -116,6 +116,7 @@ struct Wave {
 			buf[l].reserve(SBUF);
 		}
 	}
+	int list_order = 0;   // 1: listed buckets nearest first (box distance to the wave's query box), 2: by needing lanes, most first
 	int tighten_mode = 0; // 1: after every bucket thr = min(thr, max(L[31 - m], largest pending)); 2: the exact 32nd of list + pending
 	void tighten() {
 		if (!tighten_mode) return;
@@ -360,7 +361,20 @@ struct Wave {
 		}
 		if (any_pending(0)) flush();
 		phase = 2;
-		const std::vector<uint32_t> list = bfs(nbr);
+		std::vector<uint32_t> list = bfs(nbr);
+		if (list_order == 1) {
+			const Box qb = box_of(q, 64);
+			std::stable_sort(list.begin(), list.end(), [&](uint32_t x, uint32_t y) { return box_box(c.bvh[c.P + x], qb) < box_box(c.bvh[c.P + y], qb); });
+		} else if (list_order == 2) {
+			std::vector<std::pair<int, uint32_t>> v;
+			for (uint32_t leaf : list) {
+				int need = 0;
+				for (int l = 0; l < 64; ++l) need += fbits(box_point(c.bvh[c.P + leaf], q[l])) <= thr[l];
+				v.push_back({-need, leaf});
+			}
+			std::stable_sort(v.begin(), v.end(), [](const std::pair<int, uint32_t> &x, const std::pair<int, uint32_t> &y) { return x.first < y.first; });
+			for (size_t i = 0; i < v.size(); ++i) list[i] = v[i].second;
+		}
 		for (uint32_t leaf : list) {
 			const uint64_t need = need_mask(c.bvh[c.P + leaf]);
 			if (!need) continue;
@@ -533,10 +547,19 @@ int main(int argc, char **argv) {
 	struct Variant {
 		std::string name;
 		int kind, SUB, C, nbr_pre, nbr_total, lazy, tb;
-		int pair_xor = 0, sbuf = SBUF, tighten = 0;
+		int pair_xor = 0, sbuf = SBUF, tighten = 0, order = 0;
 	};
 	std::vector<Variant> vs = {
 	    {"cur nbr4 tb20", 0, 0, 0, 4, 4, 0, 20},
+	    {"cur tb12", 0, 0, 0, 4, 4, 0, 12},
+	    {"cur tb12 listed nearest first", 0, 0, 0, 4, 4, 0, 12, 0, 16, 0, 1},
+	    {"cur tb12 listed most-needed first", 0, 0, 0, 4, 4, 0, 12, 0, 16, 0, 2},
+	    {"near nbr2 tb12", 0, 0, 0, 2, 2, 0, 12, 0, 16, 0, 1},
+	    {"near nbr0 tb12", 0, 0, 0, 0, 0, 0, 12, 0, 16, 0, 1},
+	    {"near nbr6 tb12", 0, 0, 0, 6, 6, 0, 12, 0, 16, 0, 1},
+	    {"near nbr4 tb8", 0, 0, 0, 4, 4, 0, 8, 0, 16, 0, 1},
+	    {"near nbr4 tb16", 0, 0, 0, 4, 4, 0, 16, 0, 16, 0, 1},
+	    {"near nbr2 tb16", 0, 0, 0, 2, 2, 0, 16, 0, 16, 0, 1},
 	    {"cur tighten max(L[31-m],pmax)", 0, 0, 0, 4, 4, 0, 20, 0, 16, 1},
 	    {"cur tighten exact per bucket", 0, 0, 0, 4, 4, 0, 20, 0, 16, 2},
 	    {"cur pair l^32", 0, 0, 0, 4, 4, 0, 20, 32, 16},
@@ -560,7 +583,7 @@ int main(int argc, char **argv) {
 	printf("%-30s %7s %7s %7s %7s %7s %7s %7s %7s %7s %7s %7s | %8s\n", "variant", "bkts", "listed", "steps", "flush", "append", "tq", "boxt", "subt", "rounds", "retest", "idle%", "VALU~");
 	const bool only_first = getenv("SIM_ONLY_CUR") != nullptr;
 	for (const Variant &v : vs) {
-		if (only_first && &v != &vs[0]) break;
+		if (only_first && (&v - &vs[0]) > 9) break;
 		Counters total;
 #pragma omp parallel
 		{
@@ -571,6 +594,7 @@ int main(int argc, char **argv) {
 				w.pair_xor = v.pair_xor;
 				w.sbuf = v.sbuf;
 				w.tighten_mode = v.tighten;
+				w.list_order = v.order;
 				if (v.kind == 0)
 					w.run_current(v.nbr_total, v.tb);
 				else
