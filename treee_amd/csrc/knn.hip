@@ -577,6 +577,24 @@ __device__ __forceinline__ v2f pk_sub(v2f a, v2f b) {
 	asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
 	return r;
 }
+// ... with ONE element of a register pair on either side (op_sel / op_sel_hi pick the half a result lane reads): a scalar against
+// two values without first copying the scalar into both halves of a pair.  E = 0 / 1: the element of the pair.
+template <int E> __device__ __forceinline__ v2f pk_sub_elem_minus(v2f a_pair, v2f b) { // (a[E] - b.x, a[E] - b.y)
+	v2f r;
+	if constexpr (E == 0)
+		asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a_pair), "v"(b));
+	else
+		asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a_pair), "v"(b));
+	return r;
+}
+template <int E> __device__ __forceinline__ v2f pk_sub_minus_elem(v2f a, v2f b_pair) { // (a.x - b[E], a.y - b[E])
+	v2f r;
+	if constexpr (E == 0)
+		asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b_pair));
+	else
+		asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b_pair));
+	return r;
+}
 
 #ifndef TREEE_SCAN_PIPE
 #define TREEE_SCAN_PIPE 1
@@ -980,7 +998,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	// 58 buckets per wave instead of 50 and overflows the list 1.5x as often, so 4 is the default.  The boxes
 	// live in the (idle) tile memory.
 	constexpr int NG = TREEE_NG, GL = 64 / NG; // sub-boxes per wave, lanes per sub-box
-	float *gbox = &tile[0][0]; // [NG][8]: lo.xyz, tau bits, hi.xyz, pad
+	float *gbox = &tile[0][0]; // NG == 4: [lo.x | lo.y | lo.z | tau bits | hi.x | hi.y | hi.z][sub-box] (a coordinate of all four per read); else [NG][8]: lo.xyz, tau bits, hi.xyz, pad
 	uint32_t list_m = 0;
 	if constexpr (!OVF) {
 	{
@@ -1013,15 +1031,26 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			}
 		}
 		if ((lane & (GL - 1)) == 0) {
-			float *g = gbox + (lane / GL) * 8;
-			g[0] = glo[0];
-			g[1] = glo[1];
-			g[2] = glo[2];
-			g[3] = __uint_as_float(gtau);
-			g[4] = ghi[0];
-			g[5] = ghi[1];
-			g[6] = ghi[2];
-			g[7] = 0.0f;
+			if constexpr (NG == 4) {
+				float *g = gbox + lane / GL;
+				g[0] = glo[0];
+				g[4] = glo[1];
+				g[8] = glo[2];
+				g[12] = __uint_as_float(gtau);
+				g[16] = ghi[0];
+				g[20] = ghi[1];
+				g[24] = ghi[2];
+			} else {
+				float *g = gbox + (lane / GL) * 8;
+				g[0] = glo[0];
+				g[1] = glo[1];
+				g[2] = glo[2];
+				g[3] = __uint_as_float(gtau);
+				g[4] = ghi[0];
+				g[5] = ghi[1];
+				g[6] = ghi[2];
+				g[7] = 0.0f;
+			}
 		}
 	}
 #if TREEE_FRONT_CAP > TREEE_SBUF * 64
@@ -1044,6 +1073,28 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			const uint32_t node = valid ? front[cur * FRONT_CAP + idx] : 1u;
 			const float4 lo = a.bvh[2ull * node + 0], hi = a.bvh[2ull * node + 1];
 			bool hit = false;
+			if constexpr (NG == 4) {
+				// two sub-boxes per instruction (round 5): the node's corner coordinate is one ELEMENT of the register pair its load
+				// left it in, the sub-boxes' coordinates come four to a broadcast read -- 38 VALU instructions per node instead of 60;
+				// values and operation order are those of the loop below
+				const v2f lxy = {lo.x, lo.y}, lzw = {lo.z, lo.w}, hxy = {hi.x, hi.y}, hzw = {hi.z, hi.w};
+				const v4f blx = *(const v4f *)(gbox + 0), bly = *(const v4f *)(gbox + 4), blz = *(const v4f *)(gbox + 8), btau = *(const v4f *)(gbox + 12),
+				          bhx = *(const v4f *)(gbox + 16), bhy = *(const v4f *)(gbox + 20), bhz = *(const v4f *)(gbox + 24);
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const v2f glx = h ? v2f{blx.z, blx.w} : v2f{blx.x, blx.y}, gly = h ? v2f{bly.z, bly.w} : v2f{bly.x, bly.y}, glz = h ? v2f{blz.z, blz.w} : v2f{blz.x, blz.y};
+					const v2f ghx = h ? v2f{bhx.z, bhx.w} : v2f{bhx.x, bhx.y}, ghy = h ? v2f{bhy.z, bhy.w} : v2f{bhy.x, bhy.y}, ghz = h ? v2f{bhz.z, bhz.w} : v2f{bhz.x, bhz.y};
+					const v2f tau = h ? v2f{btau.z, btau.w} : v2f{btau.x, btau.y};
+					const v2f ax = pk_sub_elem_minus<0>(lxy, ghx), bx = pk_sub_minus_elem<0>(glx, hxy); // lo.x - bhi.x, blo.x - hi.x
+					const v2f ay = pk_sub_elem_minus<1>(lxy, ghy), by = pk_sub_minus_elem<1>(gly, hxy);
+					const v2f az = pk_sub_elem_minus<0>(lzw, ghz), bz = pk_sub_minus_elem<0>(glz, hzw);
+					const v2f dx = {fmaxf(fmaxf(ax.x, bx.x), 0.0f), fmaxf(fmaxf(ax.y, bx.y), 0.0f)};
+					const v2f dy = {fmaxf(fmaxf(ay.x, by.x), 0.0f), fmaxf(fmaxf(ay.y, by.y), 0.0f)};
+					const v2f dz = {fmaxf(fmaxf(az.x, bz.x), 0.0f), fmaxf(fmaxf(az.y, bz.y), 0.0f)};
+					const v2f bd = (dx * dx + dy * dy) + dz * dz;
+					hit = hit || (__float_as_uint(bd.x) <= __float_as_uint(tau.x)) || (__float_as_uint(bd.y) <= __float_as_uint(tau.y));
+				}
+			} else {
 #pragma unroll 2
 			for (int g = 0; g < NG; ++g) { // same address in every lane: LDS broadcast (unroll 2: register pressure)
 				const float4 blo = *(const float4 *)(gbox + g * 8), bhi = *(const float4 *)(gbox + g * 8 + 4);
@@ -1053,6 +1104,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 				const float bd = (dx * dx + dy * dy) + dz * dz;
 				hit = hit || (__float_as_uint(bd) <= __float_as_uint(blo.w));
 			}
+			}
 #if TREEE_AB_DOUBLE & 64
 			{
 				float lx = lo.x, ly = lo.y, lz = lo.z;
@@ -1060,7 +1112,8 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 				bool hit2 = false;
 #pragma unroll 2
 				for (int g = 0; g < NG; ++g) {
-					const float4 blo = *(const float4 *)(gbox + g * 8), bhi = *(const float4 *)(gbox + g * 8 + 4);
+					const float4 blo = NG == 4 ? make_float4(gbox[g], gbox[4 + g], gbox[8 + g], gbox[12 + g]) : *(const float4 *)(gbox + g * 8);
+					const float4 bhi = NG == 4 ? make_float4(gbox[16 + g], gbox[20 + g], gbox[24 + g], 0.0f) : *(const float4 *)(gbox + g * 8 + 4);
 					const float dx = fmaxf(fmaxf(lx - bhi.x, blo.x - hi.x), 0.0f), dy = fmaxf(fmaxf(ly - bhi.y, blo.y - hi.y), 0.0f), dz = fmaxf(fmaxf(lz - bhi.z, blo.z - hi.z), 0.0f);
 					const float bd = (dx * dx + dy * dy) + dz * dz;
 					hit2 = hit2 || (__float_as_uint(bd) <= __float_as_uint(blo.w));
