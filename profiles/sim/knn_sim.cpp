@@ -89,6 +89,7 @@ struct Counters {
 	       tq = 0 /* transposed (query, bucket) pairs */, tq_pass = 0, boxtests = 0 /* per-lane box tests, wave instructions groups */, bfs_batches = 0,
 	       listed = 0, rounds = 0, evals_useful = 0, subtests = 0, lanes_need_sum = 0, full_scans = 0, small_scans = 0, idle_lane_steps = 0, retests = 0,
 	       max_lane_appended = 0, fill_hist[17] = {}, flush_phase[4] = {}, lanes_over8_at_flush = 0, sum_final_thr_ratio = 0,
+	       pd_full = 0, pd_paired = 0, pd_inter_small = 0,
 	       gq_any = 0, gq_max4 = 0, gq_mean4 = 0, gq_max2 = 0, gq_max8 = 0, gq_buckets = 0,
 	       q_total = 0, q_zero = 0, q_low = 0, q_need_sum = 0, h_total = 0, h_zero = 0, flush_ce = 0, flush_wide = 0, flush_lo_untouched = 0, flush_lo8_untouched = 0, lanes_lo_touched = 0, nbr_need_hist[5] = {}, nbr_total = 0;
 	void add(const Counters &o) {
@@ -116,6 +117,7 @@ struct Wave {
 			buf[l].reserve(SBUF);
 		}
 	}
+	int pair_disjoint = 0; // 1: a wave-shared scan takes a second listed bucket along when the two need masks are disjoint (statistics only)
 	int list_order = 0;   // 1: listed buckets nearest first (box distance to the wave's query box), 2: by needing lanes, most first
 	int tighten_mode = 0; // 1: after every bucket thr = min(thr, max(L[31 - m], largest pending)); 2: the exact 32nd of list + pending
 	void tighten() {
@@ -375,7 +377,9 @@ struct Wave {
 			std::stable_sort(v.begin(), v.end(), [](const std::pair<int, uint32_t> &x, const std::pair<int, uint32_t> &y) { return x.first < y.first; });
 			for (size_t i = 0; i < v.size(); ++i) list[i] = v[i].second;
 		}
+		size_t list_pos = 0;
 		for (uint32_t leaf : list) {
+			const size_t my_pos = list_pos++;
 			const uint64_t need = need_mask(c.bvh[c.P + leaf]);
 			if (!need) continue;
 			k.buckets += 1;
@@ -406,6 +410,17 @@ struct Wave {
 				k.full_scans += 1;
 				quarter_stats(leaf);
 				scan_tile(leaf, ~0ull, 0);
+				// statistics: would the NEXT listed bucket that gets a wave-shared scan have had a disjoint (or nearly disjoint) mask?
+				k.pd_full += 1;
+				for (size_t jj = my_pos + 1; jj < list.size(); ++jj) {
+					uint64_t m2 = 0;
+					for (int l = 0; l < 64; ++l)
+						if (fbits(box_point(c.bvh[c.P + list[jj]], q[l])) <= thr[l]) m2 |= 1ull << l;
+					if (__builtin_popcountll(m2) < transpose_below) continue;
+					if ((m2 & need) == 0) k.pd_paired += 1;
+					else if (__builtin_popcountll(m2 & need) <= 4) k.pd_inter_small += 1;
+					break;
+				}
 			}
 			tighten();
 		}
@@ -626,6 +641,8 @@ int main(int argc, char **argv) {
 		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF && v.tighten == 0)
 			printf("   quarters walked per wave-shared bucket: any lane %.2f | busiest of 2 groups of 32 lanes %.2f | of 4 groups of 16 %.2f (mean group %.2f) | of 8 groups of 8 %.2f | buckets per wave %.2f\n",
 			       total.gq_any / total.gq_buckets, total.gq_max2 / total.gq_buckets, total.gq_max4 / total.gq_buckets, total.gq_mean4 / total.gq_buckets, total.gq_max8 / total.gq_buckets, total.gq_buckets / W);
+		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF && v.tighten == 0)
+			printf("   listed wave-shared scans per wave %.2f; the next one has a disjoint mask in %.1f%%, an overlap of <= 4 lanes in another %.1f%%\n", total.pd_full / W, 100.0 * total.pd_paired / total.pd_full, 100.0 * total.pd_inter_small / total.pd_full);
 		if (v.kind == 0 && v.pair_xor == 0 && v.sbuf == SBUF) {
 			printf("   max-lane appended per wave %.1f | flushes by phase own %.2f nbr %.2f list %.2f | lanes with > 8 pending at a flush %.2f | fill histogram:", total.max_lane_appended / W,
 			       total.flush_phase[0] / W, total.flush_phase[1] / W, total.flush_phase[2] / W, total.lanes_over8_at_flush / total.flushes);
