@@ -707,7 +707,10 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		if (!__any(live)) return; // a bucket of padding or of neighbour-only points
 	}
 	// dead lanes never pass the filter: NaN query -> NaN distance
-	if (!live) qx = __uint_as_float(0x7FC00000u);
+	// A dead lane (padding, a neighbour-only point, a slot past the queries) must never need a box nor take a candidate.  Round 5: by
+	// DATA, not by a mask ANDed into every ballot (which hipcc sent through a VGPR: select 0 / 1, compare again): its query lies at
+	// x = +inf -- every box distance and every candidate distance is then +inf (or NaN) -- and its threshold is held at 0 (below).
+	if (!live) qx = INFINITY;
 	// detach the scalars from the 16-byte record tuple they were loaded in: otherwise the register
 	// allocator spills the whole tuple and re-reads qx from scratch inside the hottest loops
 	asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(row));
@@ -716,7 +719,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	double L[SK]; // FixedSet::new (best_set.rs:20-28): (max_distance, invalid)
 #pragma unroll
 	for (int i = 0; i < SK; ++i) L[i] = key_make(a.maxbits, 0u);
-	uint32_t thr = a.maxbits; // distance bits of the current threshold entry (below)
+	uint32_t thr = live ? a.maxbits : 0u; // distance bits of the current threshold entry (below); 0 for a dead lane, for good
 	// The threshold is the distance of the list's LAST entry only when all SK are asked for.  For k < SK -- the reference's k = 31
 	// (calculations.rs:278) in the 32-entry list -- the (SK - 1)-th entry bounds the k-th from above just as well, and the search
 	// volume is that of 31 neighbours instead of 32.  Exactness is unchanged: candidates pass with `<=`, so the whole tie group of
@@ -899,7 +902,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		const float be = (ex * ex + ey * ey) + ez * ez;
 		return __ballot(live && __float_as_uint(bd) <= thr) & __ballot(live && __float_as_uint(be) <= thr);
 #endif
-		return __ballot(live && __float_as_uint(bd) <= thr);
+		return __ballot(__float_as_uint(bd) <= thr); // (a dead lane: bd = +inf against a threshold of 0)
 	};
 
 	// Quarters of a bucket some lane's search ball still reaches (a wave-uniform 4-bit mask).  Lanes 0 .. 7 fetch one corner
@@ -933,8 +936,8 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			const v2f dy = {fmaxf(fmaxf(ay.x, by.x), 0.0f), fmaxf(fmaxf(ay.y, by.y), 0.0f)};
 			const v2f dz = {fmaxf(fmaxf(az.x, bz.x), 0.0f), fmaxf(fmaxf(az.y, bz.y), 0.0f)};
 			const v2f bd = (dx * dx + dy * dy) + dz * dz;
-			m |= __ballot(live && __float_as_uint(bd.x) <= thr) ? 1u << (2 * h) : 0u;
-			m |= __ballot(live && __float_as_uint(bd.y) <= thr) ? 2u << (2 * h) : 0u;
+			m |= __ballot(__float_as_uint(bd.x) <= thr) ? 1u << (2 * h) : 0u;
+			m |= __ballot(__float_as_uint(bd.y) <= thr) ? 2u << (2 * h) : 0u;
 		}
 		return m;
 	};
@@ -979,6 +982,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			}
 			sort_net<SKT>(L);
 			thr = k_below ? key_db(L[SK - 2]) : key_db(L[SK - 1]);
+			if (!live) thr = 0u;
 			ST(if (a.thr_io && a.thr_seed && live) thr = min(thr, a.thr_io[slot]));
 			first = SK;
 		}
