@@ -744,6 +744,16 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	ST(st_t0 = st_tp = __builtin_amdgcn_s_memtime());
 #define PH(i) ST(const unsigned long long t__ = __builtin_amdgcn_s_memtime(); st_ph[i] += (uint32_t)(t__ - st_tp); st_tp = t__)
 
+	// Every distance slot of the lane's buffer at or behind its fill count holds the high word of KEY_MAX -- above every real key,
+	// so it never wins a minimum against a list entry and its position word is never looked at.  Established here, kept by flush()
+	// (round 5; before, flush() tested every slot against the fill count: a compare and a select per slot).
+	auto buffer_sentinels = [&]() __attribute__((always_inline)) {
+		if constexpr (SBUF == 16 && KEY_BIAS == 0u) {
+#pragma unroll
+			for (int s = 0; s < SBUF; ++s) buf[SBUF * 64 + s * 64 + lane] = (uint32_t)(KEY_MAX >> 32);
+		}
+	};
+	buffer_sentinels();
 	auto flush = [&]() __attribute__((always_inline)) {
 		ST(st_tf = __builtin_amdgcn_s_memtime());
 		double B[SBUF];
@@ -753,6 +763,9 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		// ADDRESS with the write offset kept sixteen per-lane addresses alive in VGPRs through the whole kernel.)
 		const uint32_t fill = (wofs - wofs0) >> 8;
 		if constexpr (SBUF == 16 && KEY_BIAS == 0u) {
+			// the branch-free append always writes its candidate at the next free slot and only COUNTS it when it passed: that one slot
+			// may hold a candidate that did not pass (for a lane outside a deferred scan's mask even one it already holds) -- sentinel
+			if (fill < (uint32_t)SBUF) *(uint32_t *)((char *)buf + wofs + DB_OFS) = (uint32_t)(KEY_MAX >> 32);
 			// every slot as ONE register pair (position, distance bits) = the key itself: ds_read2st64_b32 with the two planes as its
 			// two offsets.  Left to itself hipcc pairs two POSITIONS per read and assembles the keys with a v_mov per slot.
 			const uint32_t ba = lds_addr(&buf[lane]);
@@ -769,12 +782,10 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 			               "=&v"(B[10]), "=&v"(B[11]), "=&v"(B[12]), "=&v"(B[13]), "=&v"(B[14]), "=&v"(B[15])
 			             : "v"(ba)
 			             : "memory");
-#pragma unroll
-			for (int s = 0; s < SBUF; ++s) {
-				const unsigned long long kk = (unsigned long long)__double_as_longlong(B[s]);
-				const uint32_t hi = (uint32_t)s < fill ? (uint32_t)(kk >> 32) : (uint32_t)(KEY_MAX >> 32);
-				B[s] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | (uint32_t)kk));
-			}
+			// (no per-slot validity test: an unfilled slot HOLDS the sentinel -- see buffer_sentinels -- and the buffer is handed
+			// back that way: the sixteen stores below cost the LDS pipe what sixteen compares and selects cost the VALU, and the VALU
+			// is what this kernel is bound by)
+			buffer_sentinels();
 		} else {
 #pragma unroll
 			for (int s = 0; s < SBUF; ++s) {
@@ -1166,6 +1177,9 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		__syncthreads();
 	}
 	__syncthreads();
+#if !(TREEE_FRONT_CAP > TREEE_SBUF * 64)
+	buffer_sentinels(); // (the frontiers lay in the buffer's memory)
+#endif
 	if (overflow) { // wave-uniform; nothing has been written for this wave yet
 		if (DIAG && a.stats && lane == 0) atomicAdd(&a.stats[8], 1u);
 		// (one callee per list length class: a longer list keeps the same first k.  The callee reads the arguments from the
