@@ -62,6 +62,8 @@ def parse():
                     "sorted records through the per-workgroup LDS tile: same frame, slower")
     ap.add_argument("--splat-octree", action="store_true", help="draw the octree's Morton-sorted records (treee_splat_octree_dev, round 3) instead of the records "
                     "the kNN structure holds in Hilbert order (treee_splat_knn_dev): same frame, 0.156 vs 0.145 ms")
+    ap.add_argument("--three-calls", action="store_true", help="octree + kNN structure as treee_sort_dev / treee_knn_from_octree_dev / treee_octree_complete_dev on two "
+                    "contexts (rounds 3-5) instead of the one call treee_sort_build_knn_dev: same arrays")
     ap.add_argument("--no-overlap", action="store_true", help="build the octree's node table and the kNN structure one after the other on one stream")
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="points of the CPU-baseline sample (about 10-30 s of oracle time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,7 +183,8 @@ def main():
     curve = torch.empty((n + n // 8,), dtype=torch.float32, device=dev)
     ctx.reserve(int(n * 1.15) * 48 + (64 << 20))
     overlap = not args.no_overlap
-    side = torch.cuda.Stream(dev) if (overlap or world > 1) else None
+    # (the one-call build owns its side streams; a second context only for the three-call form and the sharded step)
+    side = torch.cuda.Stream(dev) if ((overlap and args.three_calls) or world > 1) else None
     ctx2 = T.Context(dev, side) if side is not None else None
     if side is not None:
         ctx2.reserve(int(n * 1.15) * 24 + (32 << 20))  # node table, leaf ids, LOD lists and the scans' scratch of the side stream
@@ -211,7 +214,10 @@ def main():
         # ONE Morton sort per step, two consumers: the kNN structure (its own Hilbert re-sort + box tree) is built on this
         # stream while the octree's node table -- ~50 small dependent launches -- is completed on a second one
         # (treee_sort_dev / treee_knn_from_octree_dev / treee_octree_complete_dev); --no-overlap builds them one after the other
-        if overlap:
+        if overlap and not args.three_calls:
+            # one call (treee_sort_build_knn_dev): the library owns the second stream and the order of the host's launches
+            oc, tree = stages.run("keys_sort_octree_knn_structure", lambda: T.Octree.with_knn(pts, ctx=ctx), record)
+        elif overlap:
             def both():
                 o = T.Octree(pts, ctx=ctx, defer=True)
                 t = T.KDTree.from_octree(o, ctx)

@@ -167,6 +167,9 @@ int32_t treee_curvature_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, floa
  * the two libms agree; bit 0 rows may differ by the f32 summation order (<= 1e-6 measured), bit 1 rows by another neighbour */
 int32_t treee_curvature_ties_dev(treee_ctx *ctx, const treee_knn *t, uint32_t k, float max_dist_sq,
                                  float *d_curve_out, uint8_t *d_tie_flags);
+/* host slices in and out (the form a host without device buffers binds: build, query, copy back) */
+int32_t treee_curvature_ties(const float *xyz_aos, uint64_t n, uint32_t k, float max_dist_sq,
+                             float *curve_out, uint8_t *tie_flags_out);
 /* the same, but only points whose original index is < n_own are queried; the rest (a shard's ghost points,
  * appended behind its own points) only serve as neighbours.  d_curve_out needs n_own entries. */
 int32_t treee_curvature_own_dev(treee_ctx *ctx, const treee_knn *t, uint64_t n_own, uint32_t k,
@@ -237,6 +240,13 @@ int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n,
 int32_t treee_sort_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, const float corner[3], float size,
                        treee_octree **out);
 int32_t treee_octree_complete_dev(treee_ctx *ctx, treee_octree *o, uint32_t leaf_cap, uint32_t lod_cap);
+/* The octree AND the kNN structure (treee_knn_from_octree_dev's) of one cloud from ONE call: one Morton sort, and the host's
+ * launches in the order that keeps the GPU fed -- the octree's small dependent launches on the context's auxiliary stream
+ * beside the record gather and the kNN structure's own work; the host waits for the crowded-cell flags (done long before
+ * the gather) and later for the node count, never with an empty queue.  Same arrays as the separate calls, bit for bit.
+ * Both handles are the caller's (treee_octree_free, treee_knn_free); n == 0 -> TREEE_ERR_EMPTY as KDTree::new. */
+int32_t treee_sort_build_knn_dev(treee_ctx *ctx, const float *d_xyz_aos, uint64_t n, const float corner[3], float size,
+                                 uint32_t leaf_cap, uint32_t lod_cap, treee_octree **octree_out, treee_knn **knn_out);
 int32_t treee_octree_free(treee_octree *o);
 typedef struct {
 	uint64_t n_points, n_nodes, n_lod;

@@ -134,6 +134,15 @@ inline std::vector<float> curvature(const std::vector<Point3> &data, uint32_t ne
 	if (!data.empty()) check(treee_curvature(data[0].data(), data.size(), neighbors_count, neighbors_max_distance, curve.data()));
 	return curve;
 }
+// ... with the tie flags beside it (treee_curvature_ties): a row with flag 0 is the reference's `curve`; bit 0 = equal distances inside
+// the k (another f32 summation order possible), bit 1 = the k-th and the next neighbour equally far (another member possible)
+inline std::pair<std::vector<float>, std::vector<uint8_t>> curvature_ties(const std::vector<Point3> &data, uint32_t neighbors_count = NEIGHBORS_COUNT,
+                                                                        float neighbors_max_distance = NEIGHBORS_MAX_DISTANCE) {
+	std::vector<float> curve(data.size());
+	std::vector<uint8_t> flags(data.size());
+	if (!data.empty()) check(treee_curvature_ties(data[0].data(), data.size(), neighbors_count, neighbors_max_distance, curve.data(), flags.data()));
+	return {std::move(curve), std::move(flags)};
+}
 // ... and for every segment of a segmented cloud in one pass (`segment` = the Vec<u32> kept beside the points)
 inline std::vector<float> curvature_segments(const std::vector<Point3> &data, const std::vector<uint32_t> &segment, uint32_t n_segments,
                                              uint32_t neighbors_count = NEIGHBORS_COUNT, float neighbors_max_distance = NEIGHBORS_MAX_DISTANCE) {

@@ -120,6 +120,15 @@ int main() {
 			}
 		}
 		CHECK(same > n * 0.995);
+		// the tie flags say WHICH rows may differ: every unflagged row is the reference's value bit for bit
+		const auto tied = treee::curvature_ties(points);
+		size_t flagged = 0;
+		for (size_t i = 0; i < n; ++i) {
+			CHECK(std::memcmp(&tied.first[i], &curve[i], 4) == 0);
+			flagged += tied.second[i] != 0;
+			if (!tied.second[i]) CHECK(std::memcmp(&curve[i], &want[i], 4) == 0 || (std::isnan(curve[i]) && std::isnan(want[i])));
+		}
+		CHECK(flagged < n * 0.01);
 		for (float v : {-1.0f, 0.0f, 1e-10f, 0.25f, 0.9999999f, 1.0f, 7.0f, NAN}) CHECK(treee::map_to_u32(v) == orc_map_to_u32(v));
 		// every segment at once == segment by segment
 		std::vector<uint32_t> segment(n);

@@ -514,7 +514,11 @@ def test_tie_flags_at_list_length_boundaries_and_on_segments(T, oracle):
     dist, index, counts, flags = tree.self_neighbors_dev(31, r, ties=True)
     r1_ent, r1_cnt = ref.k_nearest_batch(pts, 32, r, threads=8)
     assert np.array_equal(flags.cpu().numpy(), _flags_by_definition(r1_ent["distance"], 31, r1_cnt))
-    assert int(counts.max()) < 31 or True
+    # host slices in and out (treee_curvature_ties): the same curve and flags as the device form
+    curve_d, flags_d = tree.curvature_ties_dev(31)
+    curve_h, flags_h = T.curvature_ties(pts)
+    assert same_f32(curve_h, curve_d.cpu().numpy()) and np.array_equal(flags_h, flags_d.cpu().numpy())
+    assert same_f32(T.curvature_ties(pts[:0])[0], np.zeros(0, np.float32))
     tree.close()
     # segmented: one KD-tree per segment (calculations.rs:329)
     seg = (np.arange(len(pts)) % 3).astype(np.int32)
@@ -2730,6 +2734,51 @@ def test_deferred_octree_on_a_second_stream(T, oracle):
     ref_tree.close()
     ref.close()
     ctx_side.sync()
+
+
+def test_octree_and_knn_structure_from_one_call(T, oracle):
+    """treee_sort_build_knn_dev (Octree.with_knn): the octree of the one-call build bit for bit -- and the oracle's --, the kNN
+    structure of treee_knn_from_octree_dev row for row; on every order the structure can take (by blocks above ~1 M points, the
+    point sort below, the crowded-cell order, a cloud too small for any), with a caller's cube, twice on one context (the
+    auxiliary stream's blocks are reused), and an empty cloud is KDTree::new's error"""
+    import torch
+
+    from treee_amd import synth
+
+    rng = np.random.default_rng(99)
+    big, _ = synth.forest_cloud(1_300_000, plot=59.0)
+    mid, _ = synth.forest_cloud(300_000, plot=28.0)
+    blob = (rng.standard_normal((200_000, 3)) * np.array([5.0, 2.0, 5.0])).astype(np.float32)
+    blob[:100_000] = (blob[:100_000] * np.float32(0.0004)).astype(np.float32)  # crowded Morton cells
+    tiny = (rng.random((150, 3)) * 3).astype(np.float32)
+    cases = [("blocks", big, None, 0.0), ("points", mid, None, 0.0), ("crowded", blob, None, 0.0), ("tiny", tiny, None, 0.0),
+             ("cube", mid, np.array([-20.0, -5.0, -20.0], np.float32), 64.0)]
+    for name, pts, corner, size in cases:
+        d = torch.from_numpy(pts).cuda()
+        ref = T.Octree(d, corner=corner, size=size, leaf_cap=64, lod_cap=32)
+        ref_tree = T.KDTree.from_octree(ref)
+        ref_dist, ref_idx, ref_cnt = ref_tree.self_neighbors_dev(31)
+        ref_curve = ref_tree.curvature_dev(31)
+        for again in range(2):
+            oc, tree = T.Octree.with_knn(d, corner=corner, size=size, leaf_cap=64, lod_cap=32)
+            assert (oc.n_points, oc.n_nodes, oc.n_lod) == (ref.n_points, ref.n_nodes, ref.n_lod), name
+            assert np.array_equal(oc.corner, ref.corner) and oc.size == ref.size, name
+            for arr in ("keys", "perm", "nodes", "leaf", "lod", "sorted_xyz"):
+                assert np.array_equal(oc.array(arr).view(np.uint32), ref.array(arr).view(np.uint32)), (name, arr)
+            dist, idx, cnt = tree.self_neighbors_dev(31)
+            assert torch.equal(dist.view(torch.int32), ref_dist.view(torch.int32)) and torch.equal(idx, ref_idx) and torch.equal(cnt, ref_cnt), name
+            assert torch.equal(tree.curvature_dev(31).view(torch.int32), ref_curve.view(torch.int32)), name
+            (tree if again else oc).close()  # either order
+            (oc if again else tree).close()
+        if name == "points":  # ... and the oracle's octree
+            mn, sz = cube_of(pts)
+            sk, perm = oracle.sort_keys(oracle.morton_keys(pts, mn, sz))
+            nodes, leaf, lod = oracle.octree_build(sk, 64, 32)
+            assert np.array_equal(ref.array("nodes").view(np.uint32), nodes.view(np.uint32)) and np.array_equal(ref.array("lod"), lod)
+        ref_tree.close()
+        ref.close()
+    with pytest.raises(T.TreeeError):
+        T.Octree.with_knn(torch.zeros((0, 3), dtype=torch.float32, device="cuda"))
 
 
 def test_segments_dealt_to_ranks_give_the_same_calculations(T):

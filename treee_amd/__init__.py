@@ -11,6 +11,7 @@ from .calculations import (  # noqa: F401
     SegmentsData,
     curvature,
     curvature_segments,
+    curvature_ties,
     display_values_dev,
     map_to_u32_dev,
     segments_calculate,

@@ -91,12 +91,14 @@ SYMBOLS = {
     "treee_curvature_segments": (_i32, [_vp, _vp, _u64, _u32, _u32, _f32, _vp]),
     "treee_curvature_dev": (_i32, [_vp, _vp, _u32, _f32, _vp]),
     "treee_curvature_ties_dev": (_i32, [_vp, _vp, _u32, _f32, _vp, _vp]),
+    "treee_curvature_ties": (_i32, [_vp, _u64, _u32, _f32, _vp, _vp]),
     "treee_curvature_own_dev": (_i32, [_vp, _vp, _u64, _u32, _f32, _vp]),
     "treee_map_to_u32_dev": (_i32, [_vp, _vp, _u64, _vp]),
     "treee_sort_build": (_i32, [_vp, _u64, _vp, _f32, _u32, _u32, _pp]),
     "treee_sort_build_dev": (_i32, [_vp, _vp, _u64, _vp, _f32, _u32, _u32, _pp]),
     "treee_sort_dev": (_i32, [_vp, _vp, _u64, _vp, _f32, _pp]),
     "treee_octree_complete_dev": (_i32, [_vp, _vp, _u32, _u32]),
+    "treee_sort_build_knn_dev": (_i32, [_vp, _vp, _u64, _vp, _f32, _u32, _u32, _pp, _pp]),
     "treee_octree_free": (_i32, [_vp]),
     "treee_octree_info_get": (_i32, [_vp, C.POINTER(OctreeInfo)]),
     "treee_octree_copy": (_i32, [_vp, _i32, _vp, _u64]),

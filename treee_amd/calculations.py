@@ -26,6 +26,15 @@ def curvature(points, k=NEIGHBORS_COUNT, max_distance=NEIGHBORS_MAX_DISTANCE, ct
     return out
 
 
+def curvature_ties(points, k=NEIGHBORS_COUNT, max_distance=NEIGHBORS_MAX_DISTANCE):
+    """(curve, tie flags) of a host cloud (treee_curvature_ties): flag 0 rows are the reference's `curve`, bit 0 rows may
+    differ by the f32 summation order, bit 1 rows by another (equally far) k-th neighbour."""
+    p = host_f32(points, 3)
+    out, flags = np.zeros(len(p), np.float32), np.zeros(len(p), np.uint8)
+    _lib.check(_lib.lib().treee_curvature_ties(ptr(p), len(p), k, max_distance, ptr(out), ptr(flags)))
+    return out, flags
+
+
 def curvature_segments(points, segment, n_segments, k=NEIGHBORS_COUNT, max_distance=NEIGHBORS_MAX_DISTANCE, ctx=None):
     """`curve` of every point inside its own segment: SegmentInformation::update(calc_curve=true) for all
     segments in one pass (calculations.rs:328-373 per segment, interactive/mod.rs:224-231)."""

@@ -241,8 +241,8 @@ struct treee_ctx {
 	// on an auxiliary stream of the context.  fork(): aux waits for what `stream` holds so far.  on_aux(true/false):
 	// launches of the internal stage functions go to aux / back to `stream`.  join(): `stream` waits for aux.  Every
 	// build joins before it returns, so outside an API call the context has exactly one stream, as documented.
-	hipStream_t aux = nullptr, main_stream = nullptr;
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t aux = nullptr, aux2 = nullptr, main_stream = nullptr; // (aux2: a second side chain inside one call -- treee_sort_build_knn_dev)
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr; // (ev_mid: a point on aux the HOST waits for while aux goes on)
 	int32_t fork();
 	void on_aux(bool yes);
 	int32_t join();
@@ -342,6 +342,16 @@ std::shared_ptr<SortedCloud> octree_sorted_cloud(const treee_octree *o);
 // the records a kNN structure holds in ITS order (Hilbert index of the cell, index), the number of points it was built from,
 // and whether it is a segmented structure (records padded with (NaN, NaN, NaN, ~0u)) -- knn.hip
 std::shared_ptr<SortedCloud> knn_sorted_cloud(const treee_knn *t, uint64_t *n_points, bool *segmented);
+// the kNN structure over an already sorted cloud, enqueued on ctx's stream (knn.hip; treee_knn_from_octree_dev and
+// treee_sort_build_knn_dev are its callers)
+// (tables of the structure's order by blocks, made from the sorted keys alone: knn_block_tables_enqueue may run them on another
+// stream beside the record gather; scratch of the API call that made them)
+struct BlockTables {
+	uint32_t *d_start = nullptr, *d_end = nullptr, *d_dest_h = nullptr;
+	bool made = false;
+};
+int32_t knn_block_tables_enqueue(treee_ctx *ctx, const SortedCloud *sc, BlockTables *bt);
+int32_t knn_from_sorted_cloud(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &sc, treee_knn **out, const BlockTables *pre = nullptr);
 // hilbert_order: sort by the Hilbert index of the cell instead of its Morton key (a kNN structure's own cloud; out->hilbert)
 int32_t build_sorted_cloud(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float *corner,
                            float size, SortedCloud *out, bool fork_after_sort = false, bool hilbert_order = false);

@@ -1,5 +1,6 @@
 // context.cpp -- error state, treee_ctx (stream + workspace arena), default context.
 #include "common.h"
+#include <cstdlib>
 
 #include <mutex>
 #include <set>
@@ -218,22 +219,36 @@ using namespace treee;
 int32_t treee_ctx::fork() {
 	if (!aux) { // all three or none: a half-made set would leave later fork() / join() calls recording on a null event
 		hipStream_t s = nullptr;
-		hipEvent_t ef = nullptr, ej = nullptr;
-		hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+		hipEvent_t ef = nullptr, ej = nullptr, em = nullptr;
+		// the auxiliary stream carries chains of small dependent launches (the octree's levels) beside a kernel that fills the
+		// card (the record gather): at the default priority each of them queues behind the big kernel's waiting workgroups
+		// (flags + block tables 400 us instead of 100, measured with TREEE_TRACE_BUILD); the highest priority lets them through
+		int lo = 0, hi = 0;
+		hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+		static const bool flat = getenv("TREEE_AUX_DEFAULT_PRIORITY") != nullptr; // A/B hook
+		if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, flat ? 0 : hi);
+		hipStream_t s2 = nullptr;
+		if (e == hipSuccess) e = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, flat ? 0 : hi);
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&ef, hipEventDisableTiming);
 		if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&em, hipEventDisableTiming);
 		if (e != hipSuccess) {
+			if (em) (void)hipEventDestroy(em);
+			if (s2) (void)hipStreamDestroy(s2);
 			if (ej) (void)hipEventDestroy(ej);
 			if (ef) (void)hipEventDestroy(ef);
 			if (s) (void)hipStreamDestroy(s);
 			return set_err(TREEE_ERR_HIP, "auxiliary stream of the context: %s", hipGetErrorString(e));
 		}
 		aux = s;
+		aux2 = s2;
 		ev_fork = ef;
 		ev_join = ej;
+		ev_mid = em;
 	}
 	TREEE_HIP(hipEventRecord(ev_fork, stream));
 	TREEE_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+	TREEE_HIP(hipStreamWaitEvent(aux2, ev_fork, 0)); // (whoever uses aux2 records ev_mid behind its work and makes `stream` wait for it)
 	return TREEE_OK;
 }
 void treee_ctx::on_aux(bool yes) {
@@ -359,8 +374,11 @@ int32_t treee_ctx_destroy(treee_ctx *ctx) {
 	if (ctx->aux) {
 		(void)hipStreamSynchronize(ctx->aux);
 		(void)hipStreamDestroy(ctx->aux);
+		(void)hipStreamSynchronize(ctx->aux2);
+		(void)hipStreamDestroy(ctx->aux2);
 		(void)hipEventDestroy(ctx->ev_fork);
 		(void)hipEventDestroy(ctx->ev_join);
+		(void)hipEventDestroy(ctx->ev_mid);
 	}
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
 	if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);

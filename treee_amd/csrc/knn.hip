@@ -1927,12 +1927,30 @@ constexpr uint32_t BLK_BITS = 21, BLK_CELLS = 1u << BLK_BITS, BLK_TILE = 1536, B
 static_assert(BLK_TILE + BLOCK7_MAX <= BLK_CAP_BIG && BLOCK7_MAX <= 2048, "a tile's whole blocks must fit the larger LDS sort, a position in a block 11 bits");
 
 // start7[m] / end7[m]: the sorted positions [start, end) of the points whose key >> 9 == m (both tables zeroed before)
+// (four consecutive keys per thread, one 16-byte load: with one key per thread the launch was bound by its 58 000 workgroups,
+// 47 us for 60 MB)
+constexpr uint32_t BOUNDS_PER_THREAD = 4;
 __global__ __launch_bounds__(256) void k_block_bounds(const uint32_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ start7, uint32_t *__restrict__ end7) {
-	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-	if (i >= n) return;
-	const uint32_t m = keys[i] >> 9;
-	if (i == 0 || (keys[i - 1] >> 9) != m) start7[m] = i;
-	if (i + 1 == n || (keys[i + 1] >> 9) != m) end7[m] = i + 1u;
+	const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * BOUNDS_PER_THREAD;
+	if (i0 >= n) return;
+	uint32_t k[BOUNDS_PER_THREAD + 2]; // [0] = the key before, [5] = the key behind
+	if (i0 + BOUNDS_PER_THREAD <= n && ((uintptr_t)keys & 15u) == 0u) { // (pool blocks are 256-byte aligned, i0 is a multiple of four)
+		const uint4 v = *(const uint4 *)(keys + i0);
+		k[1] = v.x, k[2] = v.y, k[3] = v.z, k[4] = v.w;
+	} else {
+#pragma unroll
+		for (uint32_t j = 0; j < BOUNDS_PER_THREAD; ++j) k[1 + j] = i0 + j < n ? keys[i0 + j] : 0xFFFFFFFFu;
+	}
+	k[0] = i0 ? keys[i0 - 1u] : 0xFFFFFFFFu;
+	k[BOUNDS_PER_THREAD + 1] = i0 + BOUNDS_PER_THREAD < n ? keys[i0 + BOUNDS_PER_THREAD] : 0xFFFFFFFFu;
+#pragma unroll
+	for (uint32_t j = 0; j < BOUNDS_PER_THREAD; ++j) {
+		const uint32_t i = i0 + j;
+		if (i >= n) break;
+		const uint32_t m = k[1 + j] >> 9;
+		if (i == 0 || (k[j] >> 9) != m) start7[m] = i;
+		if (i + 1 == n || (k[2 + j] >> 9) != m) end7[m] = i + 1u;
+	}
 }
 // block sizes in the order of the blocks' 21-bit Hilbert prefixes
 __global__ __launch_bounds__(256) void k_block_sizes_hilbert(const uint32_t *__restrict__ start7, const uint32_t *__restrict__ end7, uint32_t *__restrict__ size_h) {
@@ -2071,23 +2089,39 @@ template <uint32_t CAP> __global__ __launch_bounds__(256) void k_block_sort(cons
 	}
 }
 
-// *taken = false (nothing written) when the cloud is too small for the tables to pay
-int32_t hilbert_order_by_blocks(treee_ctx *ctx, const SortedCloud *sc, SortedCloud *fine, bool *taken) {
+// the three tables the tile sort reads -- where a 2^-7 block starts and ends in the Morton order, where it starts in the
+// Hilbert order -- from the sorted KEYS alone (so they can be made beside the record gather: treee_sort_build_knn_dev)
+static bool blocks_pay(uint64_t n) { return n >= 4u * BLK_CELLS / 8u; } // (below ~1 M points the 2^21-entry tables cost more than the radix passes)
+int32_t block_tables_enqueue(treee_ctx *ctx, const SortedCloud *sc, BlockTables *bt) {
+	const uint32_t n = (uint32_t)sc->n;
+	hipStream_t st = ctx->stream;
+	uint32_t *d_size_h = nullptr;
+	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &bt->d_start));
+	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &bt->d_end));
+	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_size_h));
+	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &bt->d_dest_h));
+	TREEE_HIP(hipMemsetAsync(bt->d_start, 0, (size_t)BLK_CELLS * 4, st));
+	TREEE_HIP(hipMemsetAsync(bt->d_end, 0, (size_t)BLK_CELLS * 4, st));
+	hipLaunchKernelGGL(k_block_bounds, dim3(div_up(n, 256 * BOUNDS_PER_THREAD)), dim3(256), 0, st, sc->d_keys, n, bt->d_start, bt->d_end);
+	hipLaunchKernelGGL(k_block_sizes_hilbert, dim3(BLK_CELLS / 256), dim3(256), 0, st, bt->d_start, bt->d_end, d_size_h);
+	TREEE_LAUNCH_CHECK();
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_size_h, bt->d_dest_h, BLK_CELLS, nullptr));
+	bt->made = true;
+	return TREEE_OK;
+}
+
+// *taken = false (nothing written) when the cloud is too small for the tables to pay; `pre`: tables made already
+int32_t hilbert_order_by_blocks(treee_ctx *ctx, const SortedCloud *sc, SortedCloud *fine, bool *taken, const BlockTables *pre) {
 	const uint32_t n = (uint32_t)sc->n;
 	*taken = false;
-	if (n < 4u * BLK_CELLS / 8u) return TREEE_OK; // (below ~1 M points the 2^21-entry tables cost more than the radix passes)
+	if (!blocks_pay(n)) return TREEE_OK;
 	hipStream_t st = ctx->stream;
-	uint32_t *d_start = nullptr, *d_end = nullptr, *d_size_h = nullptr, *d_dest_h = nullptr;
-	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_start));
-	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_end));
-	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_size_h));
-	TREEE_TRY(ctx->alloc_t(BLK_CELLS, &d_dest_h));
-	TREEE_HIP(hipMemsetAsync(d_start, 0, (size_t)BLK_CELLS * 4, st));
-	TREEE_HIP(hipMemsetAsync(d_end, 0, (size_t)BLK_CELLS * 4, st));
-	hipLaunchKernelGGL(k_block_bounds, dim3(div_up(n, 256)), dim3(256), 0, st, sc->d_keys, n, d_start, d_end);
-	hipLaunchKernelGGL(k_block_sizes_hilbert, dim3(BLK_CELLS / 256), dim3(256), 0, st, d_start, d_end, d_size_h);
-	TREEE_LAUNCH_CHECK();
-	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_size_h, d_dest_h, BLK_CELLS, nullptr));
+	BlockTables own;
+	if (!pre || !pre->made) {
+		TREEE_TRY(block_tables_enqueue(ctx, sc, &own));
+		pre = &own;
+	}
+	uint32_t *const d_start = pre->d_start, *const d_end = pre->d_end, *const d_dest_h = pre->d_dest_h;
 	const uint32_t n_tiles = div_up(n, BLK_TILE);
 	uint32_t *d_big = nullptr; // [0] = number of tiles left to the second launch, then their indices
 	TREEE_TRY(ctx->alloc_t((size_t)n_tiles + 1, &d_big));
@@ -2109,7 +2143,7 @@ int32_t hilbert_order_by_blocks(treee_ctx *ctx, const SortedCloud *sc, SortedClo
 // low bits inside the cell as before.  Results do not depend on the order (exact search); only the tie rule names it.
 // A cloud sorted for this structure alone (treee_knn_build_dev) is sorted by the Hilbert index in the first place
 // (build_sorted_cloud's hilbert_order: one sort), and comes through here only for the crowded-cell case.
-int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &sc, std::shared_ptr<SortedCloud> *out) {
+int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &sc, std::shared_ptr<SortedCloud> *out, const BlockTables *pre = nullptr) {
 	*out = sc;
 	const uint64_t n = sc->n;
 	static const bool off = getenv("TREEE_KNN_NO_REFINE") != nullptr; // A/B and test hook
@@ -2160,7 +2194,7 @@ int32_t refine_dense_cells(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &s
 	if (trace) fprintf(stderr, "[treee knn order] n=%llu crowded=%d block7_big=%d cell_share=%.3f hilbert=%d\n", (unsigned long long)n, sc->crowded, sc->block7_big, sc->cell_share, (int)sc->hilbert);
 	if (!flag && !morton_order && !sc->hilbert && !no_blocks && sc->block7_big == 0) {
 		bool taken = false;
-		TREEE_TRY(hilbert_order_by_blocks(ctx, sc.get(), fine.get(), &taken));
+		TREEE_TRY(hilbert_order_by_blocks(ctx, sc.get(), fine.get(), &taken, pre));
 		if (taken) {
 			*out = fine;
 			return TREEE_OK;
@@ -2407,6 +2441,33 @@ int32_t knn_build_segments_cube(treee_ctx *ctx, const float *d_xyz, const uint32
 	*out = t;
 	return TREEE_OK;
 }
+// the structure over a cloud that is sorted already (one Morton sort, two consumers): its own order (refine_dense_cells) and
+// the box tree, on ctx's stream; the caller has reset the context and ordered the stream behind the sort
+int32_t knn_from_sorted_cloud(treee_ctx *ctx, const std::shared_ptr<SortedCloud> &sc, treee_knn **out, const BlockTables *pre) {
+	*out = nullptr;
+	if (sc->n == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");
+	treee_knn *t = new (std::nothrow) treee_knn;
+	if (!t) return set_err(TREEE_ERR_HIP, "kNN structure: out of host memory");
+	t->device = ctx->device;
+	t->sc = sc;
+	t->n_points = sc->n;
+	int32_t rc = refine_dense_cells(ctx, sc, &t->sc, pre); // (a private, finer-sorted copy if a Morton cell is crowded)
+	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
+	if (rc != TREEE_OK) {
+		treee_knn_free(t);
+		return rc;
+	}
+	*out = t;
+	return TREEE_OK;
+}
+// (speculative: the caller does not know yet whether the structure will order by blocks -- the flags are in flight; the tables
+// are 60 MB of key reads)
+int32_t knn_block_tables_enqueue(treee_ctx *ctx, const SortedCloud *sc, BlockTables *bt) {
+	if (!blocks_pay(sc->n) || sc->hilbert) return TREEE_OK;
+	static const bool off = getenv("TREEE_KNN_NO_BLOCKSORT") != nullptr || getenv("TREEE_KNN_NO_REFINE") != nullptr || getenv("TREEE_KNN_MORTON") != nullptr;
+	if (off) return TREEE_OK;
+	return block_tables_enqueue(ctx, sc, bt);
+}
 } // namespace treee
 extern "C" {
 
@@ -2470,17 +2531,14 @@ int32_t treee_knn_from_octree_dev(treee_ctx *ctx, const treee_octree *o, treee_k
 	std::shared_ptr<SortedCloud> sc = octree_sorted_cloud(o);
 	if (sc->n == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");
 	TREEE_HIP(hipSetDevice(ctx->device));
-	treee_knn *t = new treee_knn;
-	t->device = ctx->device;
-	t->sc = sc; // one Morton sort, two consumers
-	t->n_points = sc->n;
-	int32_t rc = ctx->reset();
-	if (rc == TREEE_OK) rc = use_begin(ctx, sc->owner, &sc->sync); // the octree may have been built on another stream
-	if (rc == TREEE_OK) rc = refine_dense_cells(ctx, sc, &t->sc); // (a private, finer-sorted copy if a Morton cell is crowded)
-	if (rc == TREEE_OK) rc = build_bvh(ctx, t);
-	if (rc == TREEE_OK) rc = use_end(ctx, sc->owner, &sc->sync);
+	TREEE_TRY(ctx->reset());
+	TREEE_TRY(use_begin(ctx, sc->owner, &sc->sync)); // the octree may have been built on another stream
+	treee_knn *t = nullptr;
+	int32_t rc = knn_from_sorted_cloud(ctx, sc, &t);
+	const int32_t e = use_end(ctx, sc->owner, &sc->sync);
+	if (rc == TREEE_OK) rc = e;
 	if (rc != TREEE_OK) {
-		treee_knn_free(t);
+		if (t) treee_knn_free(t);
 		return rc;
 	}
 	*out = t;
@@ -2688,24 +2746,36 @@ int32_t treee_knn_empty(const treee_knn *t, const float *q, uint64_t nq, float m
 	return TREEE_OK;
 }
 
-int32_t treee_curvature(const float *xyz, uint64_t n, uint32_t k, float max_dist_sq, float *curve_out) {
+static int32_t curvature_host(const char *what, const float *xyz, uint64_t n, uint32_t k, float max_dist_sq, float *curve_out, uint8_t *flags_out) {
 	if (n == 0) return TREEE_OK;
-	if (!xyz || !curve_out) return set_err(TREEE_ERR_INVALID, "treee_curvature: null argument");
+	if (!xyz || !curve_out) return set_err(TREEE_ERR_INVALID, "%s: null argument", what);
 	if (k == 0) return set_err(TREEE_ERR_INVALID, "k == 0");
 	treee_ctx *ctx = nullptr;
 	TREEE_DEFAULT_CTX(ctx);
 	treee_knn *t = nullptr;
 	TREEE_TRY(treee_knn_build(xyz, n, &t));
 	DevBuf<float> d_curve;
+	DevBuf<uint8_t> d_flags;
 	int32_t rc = d_curve.alloc(n);
-	if (rc == TREEE_OK) rc = treee_curvature_dev(ctx, t, k, max_dist_sq, d_curve.p);
+	if (rc == TREEE_OK && flags_out) rc = d_flags.alloc(n);
+	if (rc == TREEE_OK) rc = flags_out ? treee_curvature_ties_dev(ctx, t, k, max_dist_sq, d_curve.p, d_flags.p) : treee_curvature_dev(ctx, t, k, max_dist_sq, d_curve.p);
 	if (rc == TREEE_OK) {
 		hipError_t e = hipMemcpyAsync(curve_out, d_curve.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess && flags_out) e = hipMemcpyAsync(flags_out, d_flags.p, n, hipMemcpyDeviceToHost, ctx->stream);
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-		if (e != hipSuccess) rc = set_err(TREEE_ERR_HIP, "curvature copy back: %s", hipGetErrorString(e));
+		if (e != hipSuccess) rc = set_err(TREEE_ERR_HIP, "%s copy back: %s", what, hipGetErrorString(e));
 	}
 	treee_knn_free(t);
 	return rc;
+}
+
+int32_t treee_curvature(const float *xyz, uint64_t n, uint32_t k, float max_dist_sq, float *curve_out) {
+	return curvature_host("treee_curvature", xyz, n, k, max_dist_sq, curve_out, nullptr);
+}
+
+int32_t treee_curvature_ties(const float *xyz, uint64_t n, uint32_t k, float max_dist_sq, float *curve_out, uint8_t *tie_flags_out) {
+	if (n && !tie_flags_out) return set_err(TREEE_ERR_INVALID, "treee_curvature_ties: null argument");
+	return curvature_host("treee_curvature_ties", xyz, n, k, max_dist_sq, curve_out, tie_flags_out);
 }
 
 } // extern "C"

@@ -8,6 +8,7 @@
 // kernels (4 B/point written, coalesced).
 #include "comm.h"
 #include "common.h"
+#include <chrono>
 #include "shard_plan.h"
 
 using namespace treee;
@@ -181,9 +182,39 @@ int32_t build_octree(treee_ctx *ctx, treee_octree *o) {
 	const int32_t e = use_end(ctx, o->sc->owner, &o->sc->sync);
 	return rc != TREEE_OK ? rc : e;
 }
-int32_t build_octree_on(treee_ctx *ctx, treee_octree *o) {
+// What a build asks of the sorted keys for a kNN structure that will share the cloud -- is a Morton cell crowded, how many
+// cells are occupied -- and the cube when it was computed from the data: enqueued here, landing in the context's pinned
+// scalars ([0] crowded, [4..7] cube, [8..9] cells); cloud_flags_commit after whichever synchronisation follows.
+int32_t cloud_flags_enqueue(treee_ctx *ctx, SortedCloud *sc) {
+	hipStream_t st = ctx->stream;
+	uint32_t *h = ctx->h_scalars;
+	uint32_t *d_crowded = nullptr;
+	TREEE_TRY(ctx->alloc_t(1, &d_crowded));
+	TREEE_TRY(long_run_flag_dev(ctx, sc->d_keys, sc->n, d_crowded));
+	TREEE_HIP(hipMemcpyAsync(h + 0, d_crowded, 4, hipMemcpyDeviceToHost, st));
+	uint32_t *d_cells = nullptr; // occupied cells (distinct keys): lets that structure order cells instead of points
+	TREEE_TRY(ctx->alloc_t(2, &d_cells));
+	TREEE_TRY(distinct_keys_dev(ctx, sc->d_keys, sc->n, d_cells));
+	TREEE_HIP(hipMemcpyAsync(h + 8, d_cells, 8, hipMemcpyDeviceToHost, st));
+	TREEE_TRY(cube_fetch_async(ctx, sc, (float *)(h + 4)));
+	return TREEE_OK;
+}
+void cloud_flags_commit(treee_ctx *ctx, SortedCloud *sc) {
+	const uint32_t *h = ctx->h_scalars;
+	sc->crowded = (int)(h[0] & 1u);
+	sc->block7_big = (int)((h[0] >> 1) & 1u);
+	sc->cell_share = h[9] ? (float)h[8] / (float)h[9] : 1.0f;
+	cube_commit(sc, (const float *)(h + 4));
+}
+
+// The top-down build in two halves around its only host round trip (node count + LOD total, pinned scalars [1..3]):
+// everything up to the copies is enqueued by octree_levels_enqueue, the leaf ids and LOD lists by octree_finish once the
+// stream has been synchronised.
+struct OctreePending {
+	uint32_t *d_loff = nullptr;
+};
+int32_t octree_levels_enqueue(treee_ctx *ctx, treee_octree *o, OctreePending *pend) {
 	const uint64_t n = o->sc->n;
-	if (n == 0) return cube_to_host(ctx, o->sc.get());
 	hipStream_t st = ctx->stream;
 	// Capacity per level: a node is split only if it holds more than leaf_cap points, so a level has at
 	// most n/(leaf_cap+1) split nodes and the next one at most 8x that many nodes (and never more than
@@ -216,40 +247,38 @@ int32_t build_octree_on(treee_ctx *ctx, treee_octree *o) {
 		TREEE_LAUNCH_CHECK();
 	}
 	// LOD offsets, then the only host round trip of the build: node count + LOD total
-	uint32_t *d_lcnt = nullptr, *d_loff = nullptr;
+	uint32_t *d_lcnt = nullptr;
 	TREEE_TRY(ctx->alloc_t(nodes_cap, &d_lcnt));
-	TREEE_TRY(ctx->alloc_t(nodes_cap, &d_loff));
+	TREEE_TRY(ctx->alloc_t(nodes_cap, &pend->d_loff));
 	hipLaunchKernelGGL(k_oct_lod_count, dim3(div_up(nodes_cap, 256)), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * DEPTH, (uint32_t)nodes_cap, o->lod_cap, d_lcnt);
 	TREEE_LAUNCH_CHECK();
-	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_lcnt, d_loff, nodes_cap, d_total));
-	// the round trip lands in the context's pinned scalars: [0] crowded, [1..2] last level, [3] LOD total, [4..7] cube
-	uint32_t *h = ctx->h_scalars;
-	float *h_cube = (float *)(h + 4);
-	uint32_t *d_crowded = nullptr; // asked here so that a kNN structure sharing this cloud needs no round trip of its own
-	TREEE_TRY(ctx->alloc_t(1, &d_crowded));
-	TREEE_TRY(long_run_flag_dev(ctx, o->sc->d_keys, n, d_crowded));
-	TREEE_HIP(hipMemcpyAsync(h + 0, d_crowded, 4, hipMemcpyDeviceToHost, st));
-	uint32_t *d_cells = nullptr; // occupied cells (distinct keys): lets that structure order cells instead of points
-	TREEE_TRY(ctx->alloc_t(2, &d_cells));
-	TREEE_TRY(distinct_keys_dev(ctx, o->sc->d_keys, n, d_cells));
-	TREEE_HIP(hipMemcpyAsync(h + 8, d_cells, 8, hipMemcpyDeviceToHost, st));
-	TREEE_TRY(cube_fetch_async(ctx, o->sc.get(), h_cube));
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_lcnt, pend->d_loff, nodes_cap, d_total));
+	uint32_t *h = ctx->h_scalars; // pinned: [1..2] last level, [3] LOD total
 	TREEE_HIP(hipMemcpyAsync(h + 1, d_lvl + 2 * DEPTH, 8, hipMemcpyDeviceToHost, st));
 	TREEE_HIP(hipMemcpyAsync(h + 3, d_total, 4, hipMemcpyDeviceToHost, st));
-	TREEE_HIP(hipStreamSynchronize(st));
+	return TREEE_OK;
+}
+int32_t octree_finish(treee_ctx *ctx, treee_octree *o, const OctreePending &pend) {
+	const uint32_t *h = ctx->h_scalars;
 	const uint32_t lod_total = h[3];
 	o->n_nodes = (uint64_t)h[1] + h[2];
 	o->n_lod = lod_total;
-	o->sc->crowded = (int)(h[0] & 1u);
-	o->sc->block7_big = (int)((h[0] >> 1) & 1u);
-	o->sc->cell_share = h[9] ? (float)h[8] / (float)h[9] : 1.0f;
-	cube_commit(o->sc.get(), h_cube);
 	const uint32_t nn = (uint32_t)o->n_nodes;
-	TREEE_TRY(pool_alloc_t(ctx, n, &o->d_leaf));
+	TREEE_TRY(pool_alloc_t(ctx, o->sc->n, &o->d_leaf));
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)(lod_total ? lod_total : 1), &o->d_lod));
-	hipLaunchKernelGGL(k_oct_finish, dim3(div_up(nn, 4)), dim3(256), 0, st, o->d_nodes, nn, o->lod_cap, d_loff, o->d_leaf, o->d_lod);
+	hipLaunchKernelGGL(k_oct_finish, dim3(div_up(nn, 4)), dim3(256), 0, ctx->stream, o->d_nodes, nn, o->lod_cap, pend.d_loff, o->d_leaf, o->d_lod);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
+}
+int32_t build_octree_on(treee_ctx *ctx, treee_octree *o) {
+	if (o->sc->n == 0) return cube_to_host(ctx, o->sc.get());
+	OctreePending pend;
+	TREEE_TRY(octree_levels_enqueue(ctx, o, &pend));
+	// asked here so that a kNN structure sharing this cloud needs no round trip of its own
+	TREEE_TRY(cloud_flags_enqueue(ctx, o->sc.get()));
+	TREEE_HIP(hipStreamSynchronize(ctx->stream));
+	cloud_flags_commit(ctx, o->sc.get());
+	return octree_finish(ctx, o, pend);
 }
 
 
@@ -616,6 +645,101 @@ int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, con
 		return rc;
 	}
 	*out = o;
+	return TREEE_OK;
+}
+
+// One call, both consumers of the Morton sort, and the host's launches in the order that keeps the GPU fed (round 5; the three
+// calls treee_sort_dev / treee_knn_from_octree_dev / treee_octree_complete_dev on two contexts do the same work, but the host
+// waits for the sort's flags before it has enqueued anything else and the octree's ~65 small launches come last -- the
+// stage then ends when the host has finished launching them, 1.35 ms per 15 M points):
+//   stream:  sort | record gather ..................... | kNN order by blocks, boxes, dispatch table
+//   aux:          | octree levels (small dependent launches) ................ | leaf ids, LOD lists
+//   aux2:         | crowded-cell flags, cube, block tables of the kNN order |
+//   host:    enqueues all of the first two rows, waits for the FLAGS only (they are done long before the gather), enqueues
+//            the kNN structure behind the gather, then waits for the node count and enqueues the last two kernels.
+int32_t treee_sort_build_knn_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3], float size, uint32_t leaf_cap, uint32_t lod_cap,
+                                 treee_octree **octree_out, treee_knn **knn_out) {
+	if (!ctx || !octree_out || !knn_out || (n && !d_xyz)) return set_err(TREEE_ERR_INVALID, "treee_sort_build_knn_dev: null argument");
+	*octree_out = nullptr;
+	*knn_out = nullptr;
+	if (n == 0) return set_err(TREEE_ERR_EMPTY, "KDTree::new on an empty slice (the reference panics, kd_tree.rs:53,60)");
+	TREEE_HIP(hipSetDevice(ctx->device));
+	TREEE_TRY(ctx->reset());
+	treee_octree *o = new (std::nothrow) treee_octree;
+	if (!o) return set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: out of host memory");
+	o->device = ctx->device;
+	o->owner = ctx;
+	o->leaf_cap = leaf_cap ? leaf_cap : 256;
+	o->lod_cap = lod_cap ? lod_cap : 256;
+	treee_knn *t = nullptr;
+	OctreePending pend;
+	BlockTables tables;
+	// TREEE_TRACE_BUILD=1: where each stream and the host are at the call's milestones (timing events; stderr) -- a measuring hook
+	static const bool trace = getenv("TREEE_TRACE_BUILD") != nullptr;
+	struct Mark {
+		const char *what;
+		hipEvent_t ev;
+		double host_us;
+	};
+	Mark marks[12];
+	int n_marks = 0;
+	const auto t_host0 = std::chrono::steady_clock::now();
+	auto mark = [&](const char *what) {
+		if (!trace || n_marks == 12) return;
+		hipEvent_t ev = nullptr;
+		if (hipEventCreate(&ev) != hipSuccess || hipEventRecord(ev, ctx->stream) != hipSuccess) return;
+		marks[n_marks++] = {what, ev, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count()};
+	};
+	mark("start (stream)");
+	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, corner, size, o->sc.get(), /*fork_after_sort=*/true);
+	mark("sort + gather (stream)");
+	if (rc == TREEE_OK) {
+		hipStream_t const main_st = ctx->stream;
+		ctx->stream = ctx->aux2; // what the kNN structure waits for: its own chain, not behind the octree's levels
+		mark("after the sort (aux2)");
+		rc = cloud_flags_enqueue(ctx, o->sc.get());
+		mark("flags (aux2)");
+		if (rc == TREEE_OK) rc = knn_block_tables_enqueue(ctx, o->sc.get(), &tables);
+		mark("block tables (aux2)");
+		if (rc == TREEE_OK && hipEventRecord(ctx->ev_mid, ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: event");
+		ctx->stream = main_st;
+		ctx->on_aux(true);
+		if (rc == TREEE_OK) rc = octree_levels_enqueue(ctx, o, &pend);
+		mark("octree levels (aux)");
+		ctx->on_aux(false);
+		// (always: the flags' scratch is reused by the next call on this stream)
+		if (hipStreamWaitEvent(ctx->stream, ctx->ev_mid, 0) != hipSuccess && rc == TREEE_OK) rc = set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: wait");
+		if (rc == TREEE_OK && hipEventSynchronize(ctx->ev_mid) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: synchronise (flags)");
+		if (rc == TREEE_OK) {
+			cloud_flags_commit(ctx, o->sc.get());
+			mark("host has the flags (stream)");
+			if (rc == TREEE_OK) rc = knn_from_sorted_cloud(ctx, o->sc, &t, &tables); // on the context's stream, behind the gather
+			mark("kNN structure (stream)");
+		}
+		ctx->on_aux(true);
+		if (rc == TREEE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: synchronise (node count)");
+		if (rc == TREEE_OK) rc = octree_finish(ctx, o, pend);
+		mark("leaf ids + LOD lists (aux)");
+	}
+	const int32_t jr = ctx->join();
+	if (rc == TREEE_OK) rc = jr;
+	if (trace && n_marks) {
+		(void)hipStreamSynchronize(ctx->stream);
+		for (int i = 0; i < n_marks; ++i) {
+			const Mark &m = marks[i];
+			float ms = 0.0f;
+			(void)hipEventElapsedTime(&ms, marks[0].ev, m.ev);
+			fprintf(stderr, "[treee build] %-32s gpu %8.1f us   host enqueued it at %8.1f us\n", m.what, ms * 1000.0f, m.host_us);
+		}
+		for (int i = 0; i < n_marks; ++i) (void)hipEventDestroy(marks[i].ev);
+	}
+	if (rc != TREEE_OK) {
+		if (t) treee_knn_free(t);
+		treee_octree_free(o);
+		return rc;
+	}
+	*octree_out = o;
+	*knn_out = t;
 	return TREEE_OK;
 }
 

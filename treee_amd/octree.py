@@ -42,6 +42,26 @@ class Octree:
         self._h = h
         self._refresh()
 
+    @classmethod
+    def with_knn(cls, points, corner=None, size=0.0, leaf_cap=256, lod_cap=256, ctx=None):
+        """(octree, kNN structure) of one device cloud from ONE call (treee_sort_build_knn_dev): one Morton sort, the node
+        table on the context's auxiliary stream beside the record gather and the kNN structure's own work.  The same arrays as
+        `Octree(points)` + `KDTree.from_octree(octree)`."""
+        from .knn import KDTree
+
+        self = object.__new__(cls)
+        self._deferred = None
+        self.ctx = ctx or default_context(points.device)
+        c = None if corner is None else host_f32(corner).reshape(3)
+        p = dev_f32(points, 3)
+        h, hk = C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().treee_sort_build_knn_dev(self.ctx.handle, ptr(p), p.shape[0], ptr(c), size, leaf_cap, lod_cap, C.byref(h), C.byref(hk)))
+        self._h = h
+        self._refresh()
+        tree = object.__new__(KDTree)
+        tree.ctx, tree._h, tree.n, tree.device = self.ctx, hk, int(self.n_points), self.ctx.device
+        return self, tree
+
     def _refresh(self):
         info = _lib.OctreeInfo()
         _lib.check(_lib.lib().treee_octree_info_get(self._h, C.byref(info)))
