@@ -48,12 +48,31 @@ constexpr int BUCKET = 64;
 // ---- bucket AABBs and the implicit tree ---------------------------------------------------------
 // 16 lanes per bucket, 4 consecutive records per lane (64 contiguous bytes): a wave covers 4 buckets = 4 KiB, the
 // per-lane fold needs no cross-lane traffic and the butterfly has 4 steps instead of 6.
+// `up` (P >= 16 only: a workgroup's 16 leaves are then 16 whole siblings): the four tree levels above the workgroup's leaves too --
+// two inside the wave by shuffles, two through LDS -- instead of four launches of k_inner_aabb (round 5: the launches, not the
+// bytes, were their cost).  `class_key` (or null): the dispatch table's sort key of the bucket (bucket_class_key).
+#ifndef TREEE_ORDER_RANGE
+#define TREEE_ORDER_RANGE 128
+#endif
+constexpr uint32_t ORDER_RANGE = TREEE_ORDER_RANGE;
+constexpr uint32_t LEAF_UP = 4; // levels k_leaf_aabb builds above the leaves
+// five bits of size class: the exponent byte of the squared diagonal, clamped to [111, 142] (diagonals from 4 mm to 180 m; what
+// lies outside shares the end classes) -- with the three label bits an 8-bit key, ONE radix pass over the buckets (round 5;
+// the 11-bit key of rounds 1-4 took two).  Only the dispatch order depends on it, never a result.
+__device__ __forceinline__ uint32_t bucket_class_key(uint32_t b, const float (&lo)[3], const float (&hi)[3]) {
+	const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+	const float d2 = dx * dx + dy * dy + dz * dz;
+	const uint32_t e = (d2 == d2 && d2 > 0.0f) ? ((__float_as_uint(d2) >> 23) & 255u) : 0u;
+	const uint32_t c = e < 111u ? 0u : (e > 142u ? 31u : e - 111u);
+	return (((b / ORDER_RANGE) & 7u) << 5) | (31u - c);
+}
 __global__ __launch_bounds__(256) void k_leaf_aabb(const float4 *__restrict__ pts, uint32_t n, uint32_t nb, uint32_t P,
                                                     const uint32_t *__restrict__ bucket_seg /* or null */, float4 *__restrict__ bvh,
-                                                    float4 *__restrict__ sub) {
+                                                    float4 *__restrict__ sub, bool up, uint32_t *__restrict__ class_key /* or null */) {
+	__shared__ float s_up[4][8];
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	const uint32_t b = t >> 4; // bucket
-	if (b >= P) return;        // whole groups of 16 lanes leave together (the shuffles below stay inside a group)
+	if (b >= P) return;        // whole groups of 16 lanes leave together (the shuffles below stay inside a group; with `up` whole workgroups)
 	const uint32_t i0 = b * BUCKET + (t & 15u) * 4u;
 	float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
 	if (b < nb) {
@@ -91,17 +110,68 @@ __global__ __launch_bounds__(256) void k_leaf_aabb(const float4 *__restrict__ pt
 			mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
 			mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
 		}
+	// .w = segment range of the node (uint bits): [s, s] for a bucket of segment s, the empty range [~0, 0]
+	// for an unused leaf, [0, 0] everywhere when the cloud is not segmented
+	uint32_t slo = 0u, shi = 0u;
+	if (bucket_seg) {
+		const uint32_t sg = b < nb ? bucket_seg[b] : ~0u;
+		slo = sg;
+		shi = sg == ~0u ? 0u : sg;
+	}
 	if ((t & 15u) == 0) {
-		// .w = segment range of the node (uint bits): [s, s] for a bucket of segment s, the empty range [~0, 0]
-		// for an unused leaf, [0, 0] everywhere when the cloud is not segmented
-		uint32_t slo = 0u, shi = 0u;
-		if (bucket_seg) {
-			const uint32_t sg = b < nb ? bucket_seg[b] : ~0u;
-			slo = sg;
-			shi = sg == ~0u ? 0u : sg;
-		}
 		bvh[2ull * (P + b) + 0] = make_float4(mn[0], mn[1], mn[2], __uint_as_float(slo));
 		bvh[2ull * (P + b) + 1] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(shi));
+		if (class_key && b < nb) class_key[b] = bucket_class_key(b, mn, mx);
+	}
+	if (!up) return; // (uniform)
+	// every lane of a 16-lane group holds its bucket's box: node (P + b) >> l is the fold over the 2^l groups that share it
+	// (k_inner_aabb's arithmetic: fminf / fmaxf of the boxes, min / max of the segment range)
+	uint32_t node = P + b;
+#pragma unroll
+	for (int o = 16; o <= 32; o <<= 1) {
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+			mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+		}
+		slo = min(slo, (uint32_t)__shfl_xor((int)slo, o, 64));
+		shi = max(shi, (uint32_t)__shfl_xor((int)shi, o, 64));
+		node >>= 1;
+		if ((t & (2u * o - 1u)) == 0) {
+			bvh[2ull * node + 0] = make_float4(mn[0], mn[1], mn[2], __uint_as_float(slo));
+			bvh[2ull * node + 1] = make_float4(mx[0], mx[1], mx[2], __uint_as_float(shi));
+		}
+	}
+	const uint32_t w = threadIdx.x >> 6;
+	if ((threadIdx.x & 63u) == 0) {
+		s_up[w][0] = mn[0], s_up[w][1] = mn[1], s_up[w][2] = mn[2], s_up[w][3] = __uint_as_float(slo);
+		s_up[w][4] = mx[0], s_up[w][5] = mx[1], s_up[w][6] = mx[2], s_up[w][7] = __uint_as_float(shi);
+	}
+	__syncthreads();
+	if (threadIdx.x < 2) { // the two nodes over the waves (0, 1) and (2, 3); thread 0 then the one over both
+		const uint32_t x = 2u * threadIdx.x, y = x + 1u;
+		float lo3[3], hi3[3];
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			lo3[a] = fminf(s_up[x][a], s_up[y][a]);
+			hi3[a] = fmaxf(s_up[x][4 + a], s_up[y][4 + a]);
+		}
+		uint32_t l = min(__float_as_uint(s_up[x][3]), __float_as_uint(s_up[y][3])), h = max(__float_as_uint(s_up[x][7]), __float_as_uint(s_up[y][7]));
+		const uint32_t n3 = ((P + (blockIdx.x * 16u)) >> 3) + threadIdx.x;
+		bvh[2ull * n3 + 0] = make_float4(lo3[0], lo3[1], lo3[2], __uint_as_float(l));
+		bvh[2ull * n3 + 1] = make_float4(hi3[0], hi3[1], hi3[2], __uint_as_float(h));
+#pragma unroll
+		for (int a = 0; a < 3; ++a) {
+			lo3[a] = fminf(lo3[a], __shfl_xor(lo3[a], 1, 64));
+			hi3[a] = fmaxf(hi3[a], __shfl_xor(hi3[a], 1, 64));
+		}
+		l = min(l, (uint32_t)__shfl_xor((int)l, 1, 64));
+		h = max(h, (uint32_t)__shfl_xor((int)h, 1, 64));
+		if (threadIdx.x == 0) {
+			const uint32_t n4 = (P + (blockIdx.x * 16u)) >> 4;
+			bvh[2ull * n4 + 0] = make_float4(lo3[0], lo3[1], lo3[2], __uint_as_float(l));
+			bvh[2ull * n4 + 1] = make_float4(hi3[0], hi3[1], hi3[2], __uint_as_float(h));
+		}
 	}
 }
 
@@ -607,9 +677,6 @@ template <int E> __device__ __forceinline__ v2f pk_sub_minus_elem(v2f a, v2f b_p
 #endif
 #ifndef TREEE_GROUP
 #define TREEE_GROUP 52 // listed buckets whose boxes are in LDS at a time: 52 (+ the 128 bytes of quarter boxes) keeps the workgroup's LDS at 12 800 bytes (below)
-#endif
-#ifndef TREEE_ORDER_RANGE
-#define TREEE_ORDER_RANGE 128
 #endif
 #ifndef TREEE_LIST_CAP
 #define TREEE_LIST_CAP 512
@@ -1696,21 +1763,6 @@ int32_t launch_knn_on(treee_ctx *ctx, const treee_knn *t, const float *d_q, uint
 // dispatch key of a bucket: (XCD label of its Morton range) << 5 | size class, where the size class falls with the
 // exponent byte of its squared box diagonal (small key = large box) and ranges of ORDER_RANGE buckets
 // are dealt to the 8 XCD labels in turn
-constexpr uint32_t ORDER_RANGE = TREEE_ORDER_RANGE;
-__global__ __launch_bounds__(256) void k_bucket_class(const float4 *__restrict__ bvh, uint32_t nb, uint32_t P, uint32_t *__restrict__ key) {
-	const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-	if (b >= nb) return;
-	const float4 lo = bvh[2ull * (P + b) + 0], hi = bvh[2ull * (P + b) + 1];
-	const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
-	const float d2 = dx * dx + dy * dy + dz * dz;
-	// five bits of size class: the exponent byte of the squared diagonal, clamped to [111, 142] (diagonals from 4 mm to 180 m; what
-	// lies outside shares the end classes) -- with the three label bits an 8-bit key, ONE radix pass over the buckets (round 5;
-	// the 11-bit key of rounds 1-4 took two).  Only the dispatch order depends on it, never a result.
-	const uint32_t e = (d2 == d2 && d2 > 0.0f) ? ((__float_as_uint(d2) >> 23) & 255u) : 0u;
-	const uint32_t c = e < 111u ? 0u : (e > 142u ? 31u : e - 111u);
-	key[b] = (((b / ORDER_RANGE) & 7u) << 5) | (31u - c);
-}
-
 // number of buckets with XCD label x, and of those with a smaller label
 __device__ __host__ inline uint32_t order_count(uint32_t nb, uint32_t x) {
 	const uint32_t nr = nb / ORDER_RANGE, rem = nb % ORDER_RANGE;
@@ -2285,26 +2337,27 @@ int32_t build_bvh(treee_ctx *ctx, treee_knn *t, const uint32_t *d_bucket_seg = n
 	t->owner = ctx;
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->P * 2 * 2, &t->d_bvh));
 	TREEE_TRY(pool_alloc_t(ctx, (size_t)t->nb * 8, &t->d_sub));
-	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 16)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, d_bucket_seg, t->d_bvh, t->d_sub);
-	TREEE_LAUNCH_CHECK();
-	uint32_t lvl = t->P >> 1;
-	for (; lvl > INNER_TOP; lvl >>= 1) // nodes [lvl, 2*lvl)
-		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
-	if (lvl >= 1) hipLaunchKernelGGL(k_inner_aabb_top, dim3(1), dim3(INNER_TOP), 0, ctx->stream, t->d_bvh, lvl); // the levels that fit one workgroup
-	TREEE_LAUNCH_CHECK();
 	// dispatch table of the self-query kernel: a stable radix sort of the buckets by (XCD label, size class) -- an 8-bit key,
 	// one pass --, then the 8 label segments interleaved.  (On the context's auxiliary stream beside the inner levels it was
 	// measured 15 us SLOWER per 15 M-point build than behind them: the fork / join events cost more than the two short chains overlap.)
 	uint32_t *d_key = nullptr, *d_key_sorted = nullptr, *d_sorted = nullptr;
-	uint32_t longest = 0;
-	for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, order_count(t->nb, x));
-	t->n_order = 8u * longest;
 	TREEE_TRY(ctx->alloc_t(t->nb, &d_key));
 	TREEE_TRY(ctx->alloc_t(t->nb, &d_key_sorted));
 	TREEE_TRY(ctx->alloc_t(t->nb, &d_sorted));
-	TREEE_TRY(pool_alloc_t(ctx, t->n_order, &t->d_order));
-	hipLaunchKernelGGL(k_bucket_class, dim3(div_up(t->nb, 256)), dim3(256), 0, ctx->stream, t->d_bvh, t->nb, t->P, d_key);
+	static const bool no_up = getenv("TREEE_KNN_NO_LEAF_UP") != nullptr; // A/B and test hook: every inner level its own launch
+	const bool up = t->P >= 16u && !no_up;
+	hipLaunchKernelGGL(k_leaf_aabb, dim3(div_up(t->P, 16)), dim3(256), 0, ctx->stream, t->sc->d_sorted, (uint32_t)n, t->nb, t->P, d_bucket_seg, t->d_bvh, t->d_sub, up,
+	                   d_key);
 	TREEE_LAUNCH_CHECK();
+	uint32_t lvl = t->P >> (up ? 1u + LEAF_UP : 1u);
+	for (; lvl > INNER_TOP; lvl >>= 1) // nodes [lvl, 2*lvl)
+		hipLaunchKernelGGL(k_inner_aabb, dim3(div_up(lvl, 256)), dim3(256), 0, ctx->stream, t->d_bvh, lvl, lvl);
+	if (lvl >= 1) hipLaunchKernelGGL(k_inner_aabb_top, dim3(1), dim3(INNER_TOP), 0, ctx->stream, t->d_bvh, lvl); // the levels that fit one workgroup
+	TREEE_LAUNCH_CHECK();
+	uint32_t longest = 0;
+	for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, order_count(t->nb, x));
+	t->n_order = 8u * longest;
+	TREEE_TRY(pool_alloc_t(ctx, t->n_order, &t->d_order));
 	TREEE_TRY(sort_pairs_dev(ctx, d_key, nullptr, t->nb, 8, d_key_sorted, d_sorted));
 	hipLaunchKernelGGL(k_order_interleave, dim3(div_up(t->n_order, 256)), dim3(256), 0, ctx->stream, d_sorted, t->nb, t->n_order, t->d_order);
 	TREEE_LAUNCH_CHECK();

@@ -494,9 +494,46 @@ __global__ __launch_bounds__(256) void sc_apply(const uint32_t *__restrict__ in,
 	}
 }
 
+// Small arrays (the top levels of the octree: 1 ... 4 096 entries): ONE workgroup walks the tiles with a running carry -- one
+// launch instead of three.  The scans sit in chains of small dependent launches (the octree's levels: five launches per level),
+// whose length is launches x dispatch latency, not bytes (round 5, TREEE_TRACE_BUILD).
+constexpr uint32_t SC_SMALL = 4u * SC_TILE;
+__global__ __launch_bounds__(256) void sc_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n, uint32_t *__restrict__ total_out,
+                                                 const uint32_t *__restrict__ live) {
+	__shared__ uint32_t part[4];
+	if (live) n = min(n, *live);
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < n; base += SC_TILE) { // (uniform)
+		const uint32_t i0 = base + threadIdx.x * SC_ITEMS;
+		uint32_t v[SC_ITEMS], s = 0, tot;
+#pragma unroll
+		for (int j = 0; j < SC_ITEMS; ++j) {
+			v[j] = (i0 + j < n) ? in[i0 + j] : 0u;
+			s += v[j];
+		}
+		uint32_t ex = carry + block_excl_scan_256(s, part, &tot);
+#pragma unroll
+		for (int j = 0; j < SC_ITEMS; ++j) {
+			if (i0 + j < n) out[i0 + j] = ex;
+			ex += v[j];
+		}
+		carry += tot;
+	}
+	if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+// (Tried for the large arrays and dropped: tile sums and their scan from one launch, the workgroup that finishes last scanning
+// the sums -- its release fences are write-backs of an XCD's whole L2 on this chip, under a gather that fills it with dirty lines:
+// structure stage 1.24 -> 1.43 ms.)
 int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, uint32_t *d_total, const uint32_t *d_live) {
 	if (n == 0) {
 		if (d_total) TREEE_HIP(hipMemsetAsync(d_total, 0, 4, ctx->stream));
+		return TREEE_OK;
+	}
+	static const bool three = getenv("TREEE_SCAN_THREE_LAUNCHES") != nullptr; // A/B and test hook: rounds 1-4
+	if (n <= SC_SMALL && !three) {
+		hipLaunchKernelGGL(sc_small, dim3(1), dim3(256), 0, ctx->stream, d_in, d_out, (uint32_t)n, d_total, d_live);
+		TREEE_LAUNCH_CHECK();
 		return TREEE_OK;
 	}
 	uint32_t nb = div_up(n, SC_TILE);
