@@ -347,7 +347,7 @@ std::shared_ptr<SortedCloud> knn_sorted_cloud(const treee_knn *t, uint64_t *n_po
 // (tables of the structure's order by blocks, made from the sorted keys alone: knn_block_tables_enqueue may run them on another
 // stream beside the record gather; scratch of the API call that made them)
 struct BlockTables {
-	uint32_t *d_start = nullptr, *d_end = nullptr, *d_dest_h = nullptr;
+	uint32_t *d_start = nullptr, *d_end = nullptr, *d_dest_h = nullptr, *d_big = nullptr;
 	bool made = false;
 };
 int32_t knn_block_tables_enqueue(treee_ctx *ctx, const SortedCloud *sc, BlockTables *bt);

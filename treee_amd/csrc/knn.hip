@@ -2054,7 +2054,9 @@ __global__ __launch_bounds__(256) void k_block_bounds(const uint32_t *__restrict
 	}
 }
 // block sizes in the order of the blocks' 21-bit Hilbert prefixes
-__global__ __launch_bounds__(256) void k_block_sizes_hilbert(const uint32_t *__restrict__ start7, const uint32_t *__restrict__ end7, uint32_t *__restrict__ size_h) {
+// (and zeroes the counter of the tiles left to the second sort launch: a memset of four bytes is a launch of its own)
+__global__ __launch_bounds__(256) void k_block_sizes_hilbert(const uint32_t *__restrict__ start7, const uint32_t *__restrict__ end7, uint32_t *__restrict__ size_h,
+                                                              uint32_t *__restrict__ big_count) {
 	__shared__ uint16_t s_lut[24 * 8];
 	if (threadIdx.x < 24 * 8) {
 		constexpr uint16_t LUT[24 * 8] = {TREEE_HILBERT_LUT_INIT};
@@ -2062,6 +2064,7 @@ __global__ __launch_bounds__(256) void k_block_sizes_hilbert(const uint32_t *__r
 	}
 	__syncthreads();
 	const uint32_t m = blockIdx.x * 256u + threadIdx.x; // (the grid covers the table exactly)
+	if (m == 0) *big_count = 0u;
 	size_h[hilbert_of_morton_lut(m << 9, s_lut) >> 9] = end7[m] - start7[m];
 }
 // stage (K, J) of the bitonic network over CAP keys, EPT consecutive ones per thread, and all the stages behind it (the
@@ -2204,7 +2207,8 @@ int32_t block_tables_enqueue(treee_ctx *ctx, const SortedCloud *sc, BlockTables 
 	TREEE_HIP(hipMemsetAsync(bt->d_start, 0, (size_t)BLK_CELLS * 4, st));
 	TREEE_HIP(hipMemsetAsync(bt->d_end, 0, (size_t)BLK_CELLS * 4, st));
 	hipLaunchKernelGGL(k_block_bounds, dim3(div_up(n, 256 * BOUNDS_PER_THREAD)), dim3(256), 0, st, sc->d_keys, n, bt->d_start, bt->d_end);
-	hipLaunchKernelGGL(k_block_sizes_hilbert, dim3(BLK_CELLS / 256), dim3(256), 0, st, bt->d_start, bt->d_end, d_size_h);
+	TREEE_TRY(ctx->alloc_t((size_t)div_up(n, BLK_TILE) + 1, &bt->d_big)); // [0] = number of tiles left to the second launch, then their indices
+	hipLaunchKernelGGL(k_block_sizes_hilbert, dim3(BLK_CELLS / 256), dim3(256), 0, st, bt->d_start, bt->d_end, d_size_h, bt->d_big);
 	TREEE_LAUNCH_CHECK();
 	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_size_h, bt->d_dest_h, BLK_CELLS, nullptr));
 	bt->made = true;
@@ -2224,9 +2228,7 @@ int32_t hilbert_order_by_blocks(treee_ctx *ctx, const SortedCloud *sc, SortedClo
 	}
 	uint32_t *const d_start = pre->d_start, *const d_end = pre->d_end, *const d_dest_h = pre->d_dest_h;
 	const uint32_t n_tiles = div_up(n, BLK_TILE);
-	uint32_t *d_big = nullptr; // [0] = number of tiles left to the second launch, then their indices
-	TREEE_TRY(ctx->alloc_t((size_t)n_tiles + 1, &d_big));
-	TREEE_HIP(hipMemsetAsync(d_big, 0, 4, st));
+	uint32_t *const d_big = pre->d_big;
 	hipLaunchKernelGGL(k_block_sort<BLK_CAP>, dim3(n_tiles), dim3(256), 0, st, sc->d_keys, sc->d_sorted, n, d_start, d_end, d_dest_h, fine->d_keys, fine->d_perm,
 	                   fine->d_sorted, d_big);
 	hipLaunchKernelGGL(k_block_sort<BLK_CAP_BIG>, dim3(std::min(n_tiles, 512u)), dim3(256), 0, st, sc->d_keys, sc->d_sorted, n, d_start, d_end, d_dest_h, fine->d_keys,

@@ -98,14 +98,20 @@ __global__ __launch_bounds__(256) void k_oct_split(const uint32_t *__restrict__ 
 	}
 }
 
+// `host_pair` (or null; the last level only): pinned host words that receive the next level's descriptor too -- the build's round
+// trip then needs no copy behind the kernels
 __global__ __launch_bounds__(256) void k_oct_emit(treee_octree_node *__restrict__ nodes, uint32_t *__restrict__ lvl,
                                                    const uint32_t *__restrict__ child_off, const uint32_t *__restrict__ bounds,
-                                                   const uint32_t *__restrict__ total) {
+                                                   const uint32_t *__restrict__ total, uint32_t *__restrict__ host_pair) {
 	const uint32_t lvl_begin = lvl[0], lvl_count = lvl[1];
 	const uint32_t t = blockIdx.x * 256u + threadIdx.x;
 	if (t == 0) { // descriptor of the next level
 		lvl[2] = lvl_begin + lvl_count;
 		lvl[3] = *total;
+		if (host_pair) {
+			host_pair[0] = lvl_begin + lvl_count;
+			host_pair[1] = *total;
+		}
 	}
 	const uint32_t p = t >> 3, c = t & 7u;
 	if (p >= lvl_count) return;
@@ -243,7 +249,8 @@ int32_t octree_levels_enqueue(treee_ctx *ctx, treee_octree *o, OctreePending *pe
 		hipLaunchKernelGGL(k_oct_split, dim3(grid), dim3(256), 0, st, o->sc->d_keys, o->d_nodes, d_lvl + 2 * level, cap, o->leaf_cap, d_cnt, d_bounds);
 		TREEE_LAUNCH_CHECK();
 		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_cnt, d_off, cap, d_total, d_lvl + 2 * level + 1)); // only the level's nodes
-		hipLaunchKernelGGL(k_oct_emit, dim3(grid), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * level, d_off, d_bounds, d_total);
+		hipLaunchKernelGGL(k_oct_emit, dim3(grid), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * level, d_off, d_bounds, d_total,
+		                   level + 1 == DEPTH ? ctx->h_scalars + 1 : (uint32_t *)nullptr); // pinned [1..2]: the last level's (begin, count)
 		TREEE_LAUNCH_CHECK();
 	}
 	// LOD offsets, then the only host round trip of the build: node count + LOD total
@@ -252,10 +259,8 @@ int32_t octree_levels_enqueue(treee_ctx *ctx, treee_octree *o, OctreePending *pe
 	TREEE_TRY(ctx->alloc_t(nodes_cap, &pend->d_loff));
 	hipLaunchKernelGGL(k_oct_lod_count, dim3(div_up(nodes_cap, 256)), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * DEPTH, (uint32_t)nodes_cap, o->lod_cap, d_lcnt);
 	TREEE_LAUNCH_CHECK();
-	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_lcnt, pend->d_loff, nodes_cap, d_total));
-	uint32_t *h = ctx->h_scalars; // pinned: [1..2] last level, [3] LOD total
-	TREEE_HIP(hipMemcpyAsync(h + 1, d_lvl + 2 * DEPTH, 8, hipMemcpyDeviceToHost, st));
-	TREEE_HIP(hipMemcpyAsync(h + 3, d_total, 4, hipMemcpyDeviceToHost, st));
+	// (the scan's total goes straight to the pinned word [3]: the kernels write the host's copy themselves, no copy is queued)
+	TREEE_TRY(exclusive_scan_u32_dev(ctx, d_lcnt, pend->d_loff, nodes_cap, ctx->h_scalars + 3));
 	return TREEE_OK;
 }
 int32_t octree_finish(treee_ctx *ctx, treee_octree *o, const OctreePending &pend) {
@@ -541,7 +546,7 @@ int32_t shard_build(treee_ctx *ctx, treee_comm *comm, const float *d_xyz, uint64
 		hipLaunchKernelGGL(k_oct_split, dim3(grid), dim3(256), 0, st, sc->d_keys, o->d_nodes, d_lvl + 2 * level, cap, o->leaf_cap, d_cnt, d_bounds);
 		TREEE_LAUNCH_CHECK();
 		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_cnt, d_off, cap, d_total, d_lvl + 2 * level + 1));
-		hipLaunchKernelGGL(k_oct_emit, dim3(grid), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * level, d_off, d_bounds, d_total);
+		hipLaunchKernelGGL(k_oct_emit, dim3(grid), dim3(256), 0, st, o->d_nodes, d_lvl + 2 * level, d_off, d_bounds, d_total, (uint32_t *)nullptr);
 		TREEE_LAUNCH_CHECK();
 	}
 	uint32_t *d_lcnt = nullptr, *d_loff = nullptr, *d_sums = nullptr;
