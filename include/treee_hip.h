@@ -36,10 +36,10 @@
  *     treee_octree_free, and work the CALLER enqueues on them from other streams must be complete (or
  *     ordered before the owner's stream) when the handle is freed
  *   - a context is used by one host thread at a time; different contexts may be used concurrently
- *   - INSIDE a build (treee_sort_build_dev, treee_sort_build_knn_dev) a context may run independent chains of small
- *     launches on up to two auxiliary streams of its own (created on first use at the highest stream priority, so that a
- *     small launch does not queue behind the workgroups of a kernel that fills the card); every such call joins them into
- *     the context's stream before it returns: outside an API call a context has exactly one stream, the caller's
+ *   - INSIDE a build (treee_sort_build_dev, treee_sort_build_knn_dev) a context may run an independent chain of small
+ *     launches on an auxiliary stream of its own (created on first use at the highest stream priority, so that a small
+ *     launch does not queue behind the workgroups of a kernel that fills the card); every such call joins it into the
+ *     context's stream before it returns: outside an API call a context has exactly one stream, the caller's
  */
 #ifndef TREEE_HIP_H
 #define TREEE_HIP_H

@@ -241,7 +241,7 @@ struct treee_ctx {
 	// on an auxiliary stream of the context.  fork(): aux waits for what `stream` holds so far.  on_aux(true/false):
 	// launches of the internal stage functions go to aux / back to `stream`.  join(): `stream` waits for aux.  Every
 	// build joins before it returns, so outside an API call the context has exactly one stream, as documented.
-	hipStream_t aux = nullptr, aux2 = nullptr, main_stream = nullptr; // (aux2: a second side chain inside one call -- treee_sort_build_knn_dev)
+	hipStream_t aux = nullptr, main_stream = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr; // (ev_mid: a point on aux the HOST waits for while aux goes on)
 	int32_t fork();
 	void on_aux(bool yes);

@@ -658,8 +658,7 @@ int32_t treee_sort_build_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, con
 // waits for the sort's flags before it has enqueued anything else and the octree's ~65 small launches come last -- the
 // stage then ends when the host has finished launching them, 1.35 ms per 15 M points):
 //   stream:  sort | record gather ..................... | kNN order by blocks, boxes, dispatch table
-//   aux:          | octree levels (small dependent launches) ................ | leaf ids, LOD lists
-//   aux2:         | crowded-cell flags, cube, block tables of the kNN order |
+//   aux:          | crowded-cell flags, cube, block tables of the kNN order | octree levels (small dependent launches) ... | leaf ids, LOD lists
 //   host:    enqueues all of the first two rows, waits for the FLAGS only (they are done long before the gather), enqueues
 //            the kNN structure behind the gather, then waits for the node count and enqueues the last two kernels.
 int32_t treee_sort_build_knn_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n, const float corner[3], float size, uint32_t leaf_cap, uint32_t lod_cap,
@@ -699,20 +698,17 @@ int32_t treee_sort_build_knn_dev(treee_ctx *ctx, const float *d_xyz, uint64_t n,
 	int32_t rc = build_sorted_cloud(ctx, d_xyz, n, corner, size, o->sc.get(), /*fork_after_sort=*/true);
 	mark("sort + gather (stream)");
 	if (rc == TREEE_OK) {
-		hipStream_t const main_st = ctx->stream;
-		ctx->stream = ctx->aux2; // what the kNN structure waits for: its own chain, not behind the octree's levels
-		mark("after the sort (aux2)");
-		rc = cloud_flags_enqueue(ctx, o->sc.get());
-		mark("flags (aux2)");
-		if (rc == TREEE_OK) rc = knn_block_tables_enqueue(ctx, o->sc.get(), &tables);
-		mark("block tables (aux2)");
-		if (rc == TREEE_OK && hipEventRecord(ctx->ev_mid, ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: event");
-		ctx->stream = main_st;
 		ctx->on_aux(true);
+		mark("after the sort (aux)");
+		rc = cloud_flags_enqueue(ctx, o->sc.get());
+		mark("flags (aux)");
+		if (rc == TREEE_OK) rc = knn_block_tables_enqueue(ctx, o->sc.get(), &tables);
+		mark("block tables (aux)");
+		if (rc == TREEE_OK && hipEventRecord(ctx->ev_mid, ctx->stream) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: event");
 		if (rc == TREEE_OK) rc = octree_levels_enqueue(ctx, o, &pend);
 		mark("octree levels (aux)");
 		ctx->on_aux(false);
-		// (always: the flags' scratch is reused by the next call on this stream)
+		// (the kNN structure reads the block tables: behind the point of aux where they are made, not behind the levels)
 		if (hipStreamWaitEvent(ctx->stream, ctx->ev_mid, 0) != hipSuccess && rc == TREEE_OK) rc = set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: wait");
 		if (rc == TREEE_OK && hipEventSynchronize(ctx->ev_mid) != hipSuccess) rc = set_err(TREEE_ERR_HIP, "treee_sort_build_knn_dev: synchronise (flags)");
 		if (rc == TREEE_OK) {
