@@ -828,8 +828,23 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		}
 	};
 	buffer_sentinels();
+	// Wave priorities (round 5): a wave in a scan is a chain of dependent steps -- broadcast read, distances, compare, store -- with
+	// little to issue at any moment; a wave in a merge has 300 independent VALU instructions.  With the merging waves at the LOWER
+	// priority the scanning ones get their few ready instructions issued at once and the merges fill what is left: 6.66 -> 6.53 ms
+	// (the other way round: 7.07); the first sort and the epilogue at the merges' priority too: 6.50 -> 6.43.  Which two levels does
+	// not matter (1 / 0, 2 / 0, 3 / 0, 3 / 1 within the noise); the BFS above or below the scans costs 0.05 ms either way.
+	// -DTREEE_PRIO_SCAN=0 is the kernel without priorities.
+#ifndef TREEE_PRIO_SCAN
+#define TREEE_PRIO_SCAN 1
+#endif
+#ifndef TREEE_PRIO_FLUSH
+#define TREEE_PRIO_FLUSH 0
+#endif
+	constexpr int PRIO_SCAN = TREEE_PRIO_SCAN, PRIO_FLUSH = TREEE_PRIO_FLUSH;
+	__builtin_amdgcn_s_setprio(PRIO_SCAN);
 	auto flush = [&]() __attribute__((always_inline)) {
 		ST(st_tf = __builtin_amdgcn_s_memtime());
+		__builtin_amdgcn_s_setprio(PRIO_FLUSH);
 		double B[SBUF];
 		// slots at or behind the lane's fill count carry a key above every real one: distance bits 0x7FEFFFFF (the high word of
 		// KEY_MAX) over whatever position the slot last held -- such a key never wins a minimum against a list entry, so its low
@@ -884,6 +899,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 		}
 		ST(st_flush++);
 		wofs = wofs0;
+		__builtin_amdgcn_s_setprio(PRIO_SCAN);
 		ST(st_ph[6] += (uint32_t)(__builtin_amdgcn_s_memtime() - st_tf));
 	};
 
@@ -957,7 +973,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 					nx = *(const v4f *)&tile[0][cn];
 					ny = *(const v4f *)&tile[1][cn];
 					nz = *(const v4f *)&tile[2][cn];
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // keeps the reads above the append
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // keeps the reads above the append (behind it: no gain, 6.68 / 6.68 ms)
 				}
 				if constexpr (FASTBUF) {
 					// The append of the four candidates, by hand (round 5).  Per candidate: v_cmpx narrows EXEC to the lanes it passes
@@ -1107,7 +1123,9 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 				L[j] = d0 < a.maxbits ? key_make(d0, base + j) : key_make(a.maxbits, 0u); // strict `<` (best_set.rs:20-28)
 				L[j + 1] = d1 < a.maxbits ? key_make(d1, base + j + 1) : key_make(a.maxbits, 0u);
 			}
+			__builtin_amdgcn_s_setprio(PRIO_FLUSH); // (the first sort: 191 compare-exchanges, as dense as a merge)
 			sort_net<SKT>(L);
+			__builtin_amdgcn_s_setprio(PRIO_SCAN);
 			thr = k_below ? key_db(L[SK - 2]) : key_db(L[SK - 1]);
 			if (!live) thr = 0u;
 			ST(if (a.thr_io && a.thr_seed && live) thr = min(thr, a.thr_io[slot]));
@@ -1506,6 +1524,7 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 	if (!live) return;
 
 	PH(5);
+	__builtin_amdgcn_s_setprio(PRIO_FLUSH); // (the epilogue: straight-line arithmetic)
 	const uint32_t k = a.k;
 	// valid entries among the first k: the list is ascending and an unused entry carries max_distance, so the valid ones lead --
 	// count = min(k, valid entries of the whole list).  (Written as `s < k && valid` per entry, the 32 wave-uniform conditions
