@@ -984,7 +984,8 @@ template <bool DIAG, bool SEG, int SKT, bool OVF> __device__ __forceinline__ voi
 					// 6.64 ms per 15 M points, a fifth of what the instruction count promised -- the trip is one dependent chain through the
 					// LDS and the compare's EXEC write; skipping store and increment when no lane passed, s_cbranch_execz, gave nothing;
 					// the broadcast reads issued by hand so that the trip's head waits for lgkmcnt(4) -- the reads, not the appends behind
-					// them -- cost 0.4 ms: twelve registers the compiler cannot see in flight are twelve it copies around.)
+					// them -- cost 0.4 ms: twelve registers the compiler cannot see in flight are twelve it copies around; with the run's
+					// first reads waited for where they are issued and ONE wait at the trip's head, still +0.1 ms.)
 					const uint32_t p0 = base + (uint32_t)c0; // (wave-uniform)
 					uint64_t P01, P23, sv;
 					asm("v_pk_mov_b32 %0, %1, %1 op_sel:[0,1]" : "=v"(P01) : "s"(((uint64_t)(p0 + 1u) << 32) | (uint64_t)p0));
