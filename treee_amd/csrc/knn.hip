@@ -2588,6 +2588,7 @@ int32_t knn_from_sorted_cloud(treee_ctx *ctx, const std::shared_ptr<SortedCloud>
 // are 60 MB of key reads)
 int32_t knn_block_tables_enqueue(treee_ctx *ctx, const SortedCloud *sc, BlockTables *bt) {
 	if (!blocks_pay(sc->n) || sc->hilbert) return TREEE_OK;
+	if (sc->n > (64ull << 20)) return TREEE_OK; // (a cloud this large rarely orders by blocks -- some 2^-7 block holds 2 048 points --: no guess, the tables are made if the flags ask)
 	static const bool off = getenv("TREEE_KNN_NO_BLOCKSORT") != nullptr || getenv("TREEE_KNN_NO_REFINE") != nullptr || getenv("TREEE_KNN_MORTON") != nullptr;
 	if (off) return TREEE_OK;
 	return block_tables_enqueue(ctx, sc, bt);

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(256) void sc_apply(const uint32_t *__restrict__ in,
 // launch instead of three.  The scans sit in chains of small dependent launches (the octree's levels: five launches per level),
 // whose length is launches x dispatch latency, not bytes (round 5, TREEE_TRACE_BUILD).
 constexpr uint32_t SC_SMALL = 4u * SC_TILE;
+constexpr uint32_t SC_SUMS_ONE_GROUP = 16384; // tile sums one workgroup scans by itself (sc_scan_sums)
 __global__ __launch_bounds__(256) void sc_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n, uint32_t *__restrict__ total_out,
                                                  const uint32_t *__restrict__ live) {
 	__shared__ uint32_t part[4];
@@ -540,7 +541,13 @@ int32_t exclusive_scan_u32_dev(treee_ctx *ctx, const uint32_t *d_in, uint32_t *d
 	uint32_t *d_sums = nullptr;
 	TREEE_TRY(ctx->alloc_t(nb, &d_sums));
 	hipLaunchKernelGGL(sc_reduce, dim3(nb), dim3(256), 0, ctx->stream, d_in, (uint32_t)n, d_sums, d_live);
-	hipLaunchKernelGGL(sc_scan_sums, dim3(1), dim3(256), 0, ctx->stream, d_sums, nb, d_total);
+	if (nb > SC_SUMS_ONE_GROUP) {
+		// (above ~17 M entries the tile sums are an array worth scanning in parallel themselves -- in place: every thread reads its own
+		// entries before it writes them.  One workgroup walking 146 000 sums of a 150 M-entry scan took 90 us, nine times per build.)
+		TREEE_TRY(exclusive_scan_u32_dev(ctx, d_sums, d_sums, nb, d_total, nullptr));
+	} else {
+		hipLaunchKernelGGL(sc_scan_sums, dim3(1), dim3(256), 0, ctx->stream, d_sums, nb, d_total);
+	}
 	hipLaunchKernelGGL(sc_apply, dim3(nb), dim3(256), 0, ctx->stream, d_in, d_out, (uint32_t)n, d_sums, d_live);
 	TREEE_LAUNCH_CHECK();
 	return TREEE_OK;
