@@ -593,7 +593,11 @@ __global__ __launch_bounds__(256) void k_long_run(const uint32_t *__restrict__ k
 	uint32_t bits = 0u;
 	if (i + LONG_RUN < n && keys[i] == keys[i + LONG_RUN]) bits |= 1u;
 	if (i + BLOCK7_PROBE < n && (keys[i] >> 9) == (keys[i + BLOCK7_PROBE] >> 9)) bits |= 2u;
-	if (bits && (*flag & bits) != bits) atomicOr(flag, bits); // (the plain read keeps a crowded cloud from queueing its atomics on one word)
+	// (the read keeps a crowded cloud from queueing its atomics on one word -- read at agent scope: a plain load is served from the CU's
+	// L1, which never sees the other workgroups' atomics, and 1 G crowded points then queued 2.4 ms of them; one atomic per wave)
+	const uint64_t any1 = __ballot((bits & 1u) != 0u), any2 = __ballot((bits & 2u) != 0u);
+	const uint32_t wave_bits = (any1 ? 1u : 0u) | (any2 ? 2u : 0u);
+	if (wave_bits && (threadIdx.x & 63u) == 0u && (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & wave_bits) != wave_bits) atomicOr(flag, wave_bits);
 }
 
 int32_t long_run_flag_dev(treee_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint32_t *d_flag) {
