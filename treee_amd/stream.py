@@ -28,7 +28,7 @@ import numpy as np
 
 from . import _lib
 from .context import Context, F32_MAX, ptr
-from .knn import KDTree
+from .knn import KDTree  # noqa: F401  (the handle type Octree.with_knn returns)
 from .octree import Octree
 
 
@@ -208,12 +208,9 @@ class TileStream(_Staging):
         self._init_staging(device, max_points, max_stride)
         torch = self.torch
         self.ctx = Context(self.device.index, self.compute)
-        self.ctx.reserve(int(max_points * 1.1) * 64 + (64 << 20))
-        # with kNN on, a tile's octree node table is completed on a side stream under the kNN structure's own build
-        self.side = torch.cuda.Stream(self.device) if knn_k else None
-        self.ctx2 = Context(self.device.index, self.side) if knn_k else None
-        if self.ctx2 is not None:
-            self.ctx2.reserve(int(max_points * 1.1) * 24 + (32 << 20))
+        # (with kNN on, a tile's octree node table is completed beside the kNN structure's own build by the ONE call
+        # treee_sort_build_knn_dev -- the library's auxiliary stream; rounds 3-5a: a second context on a torch side stream)
+        self.ctx.reserve(int(max_points * 1.1) * (88 if knn_k else 64) + (96 << 20))
         self.xyz = torch.empty((self.max_points, 3), dtype=torch.float32, device=self.device)
         self.value = torch.empty((self.max_points,), dtype=torch.int32, device=self.device)
         self.curve = torch.empty((self.max_points,), dtype=torch.float32, device=self.device) if knn_k else None
@@ -248,10 +245,7 @@ class TileStream(_Staging):
                                                             ptr(tile.offset), ptr(tile.center), ptr(xyz)))
                 self.consumed[slot].record(self.compute)  # the staging buffer may be overwritten from here on
                 if self.knn_k:
-                    oc = Octree(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx, defer=True)
-                    tree = KDTree.from_octree(oc, self.ctx)
-                    oc.complete(self.ctx2)
-                    self.compute.wait_stream(self.side)
+                    oc, tree = Octree.with_knn(xyz, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx)
                     tree.curvature_dev(self.knn_k, F32_MAX, self.ctx, out=self.curve[:n])
                     _lib.check(lib.treee_map_to_u32_dev(self.ctx.handle, ptr(self.curve), n, ptr(self.value)))
                     tree.close()
@@ -277,8 +271,6 @@ class TileStream(_Staging):
     def close(self):
         if self.pool is not None:
             self.pool.shutdown()
-        if self.ctx2 is not None:
-            self.ctx2.close()
         self.ctx.close()
 
 
@@ -299,8 +291,6 @@ class WholeCloudStream(_Staging):
         if self.capacity >= (1 << 31):
             raise OverflowError(f"{self.capacity} points: a cloud holds at most 2^31 - 1 points (include/treee_hip.h)")
         self.ctx = Context(self.device.index, self.compute)
-        self.side = torch.cuda.Stream(self.device)
-        self.ctx2 = Context(self.device.index, self.side)
         self.xyz = torch.empty((self.capacity, 3), dtype=torch.float32, device=self.device)
         self.value = torch.empty((self.capacity,), dtype=torch.int32, device=self.device)
         self.curve = torch.empty((self.capacity,), dtype=torch.float32, device=self.device) if knn_k else None
@@ -336,10 +326,7 @@ class WholeCloudStream(_Staging):
                 return res
             cloud = self.xyz[:total]
             if self.knn_k:
-                oc = Octree(cloud, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx, defer=True)
-                tree = KDTree.from_octree(oc, self.ctx)
-                oc.complete(self.ctx2)
-                self.compute.wait_stream(self.side)
+                oc, tree = Octree.with_knn(cloud, leaf_cap=self.leaf_cap, lod_cap=self.lod_cap, ctx=self.ctx)
                 ev["structure"].record(self.compute)
                 tree.curvature_dev(self.knn_k, F32_MAX, self.ctx, out=self.curve[:total])
                 _lib.check(lib.treee_map_to_u32_dev(self.ctx.handle, ptr(self.curve), total, ptr(self.value)))
@@ -366,7 +353,6 @@ class WholeCloudStream(_Staging):
         self._drop()
         if self.pool is not None:
             self.pool.shutdown()
-        self.ctx2.close()
         self.ctx.close()
 
 
