@@ -105,6 +105,51 @@ __global__ __launch_bounds__(256) void k_seg_aabb_direct(const float *__restrict
 		if (better & (8u << d)) atomicMax(&aabb[(size_t)sg * AABB_ROW + 3u + d], o[d]);
 	}
 }
+// The dense levels of the ladder with the table of extremes in LDS (round 5).  The kernel above spends its time in the three
+// per-lane gathers of a point's row (64 lanes, 64 segments, a table that does not fit the L1: 340 us for the full pass over 15 M
+// points, 0.7 TB/s).  Here a workgroup copies the table as the samples left it (24 bytes per segment: up to AABB_LDS_SEGMENTS of
+// them), walks its share of the points against that copy -- LDS gathers --, and what beats the copy goes to the copy (LDS atomics: the
+// workgroup's later points see it) and to the global table (the same atomicMin / atomicMax on the same ordered images as above, so
+// the result is the same extremes whatever the order).  `present` is marked the first time a workgroup meets a segment.
+constexpr uint32_t AABB_LDS_SEGMENTS = 2688, AABB_LDS_THREADS = 1024; // 2688 x 24 B = 63 KiB + 336 B of seen bits: two workgroups per CU
+__global__ __launch_bounds__(AABB_LDS_THREADS) void k_seg_aabb_lds(const float *__restrict__ xyz, const uint32_t *__restrict__ seg, uint32_t n, uint32_t nseg,
+                                                                    uint32_t stride, uint32_t run, uint32_t *aabb, uint32_t *present) {
+	__shared__ uint32_t s_row[AABB_LDS_SEGMENTS * 6];
+	__shared__ uint32_t s_seen[(AABB_LDS_SEGMENTS + 31) / 32];
+	for (uint32_t i = threadIdx.x; i < nseg * 6u; i += AABB_LDS_THREADS) s_row[i] = aabb[(size_t)(i / 6u) * AABB_ROW + i % 6u];
+	for (uint32_t i = threadIdx.x; i < (nseg + 31u) / 32u; i += AABB_LDS_THREADS) s_seen[i] = 0u;
+	__syncthreads();
+	const uint64_t total = ((uint64_t)n + (uint64_t)stride * run - 1u) / ((uint64_t)stride * run) * run; // threads' worth of sample points (an upper bound)
+	for (uint64_t t = (uint64_t)blockIdx.x * AABB_LDS_THREADS + threadIdx.x; t < total; t += (uint64_t)gridDim.x * AABB_LDS_THREADS) {
+		const uint64_t i64 = (t / run) * run * stride + t % run; // (the sample of k_seg_aabb_direct)
+		if (i64 >= n) continue;
+		const uint32_t i = (uint32_t)i64, sg = seg[i];
+		if (sg >= nseg) continue; // (reported by k_check_segments)
+		if (!((s_seen[sg >> 5] >> (sg & 31u)) & 1u)) {
+			if (!((atomicOr(&s_seen[sg >> 5], 1u << (sg & 31u)) >> (sg & 31u)) & 1u)) present[sg] = 1u;
+		}
+		const uint32_t *row = &s_row[sg * 6u];
+		uint32_t o[3], better = 0;
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			const float v = xyz[3ull * i + d];
+			o[d] = f2ord(v);
+			if (v == v) better |= (o[d] < row[d] ? 1u << d : 0u) | (o[d] > row[3 + d] ? 8u << d : 0u); // (f32::min / f32::max drop a NaN operand)
+		}
+		if (better == 0u) continue;
+#pragma unroll
+		for (int d = 0; d < 3; ++d) {
+			if (better & (1u << d)) {
+				atomicMin(&s_row[sg * 6u + d], o[d]);
+				atomicMin(&aabb[(size_t)sg * AABB_ROW + d], o[d]);
+			}
+			if (better & (8u << d)) {
+				atomicMax(&s_row[sg * 6u + 3u + d], o[d]);
+				atomicMax(&aabb[(size_t)sg * AABB_ROW + 3u + d], o[d]);
+			}
+		}
+	}
+}
 // decode; an empty segment is (0, 0, 0) (calculations.rs:135-136), a segment whose every value along an axis is NaN keeps NaN
 // (min(NaN, NaN)); slice count of the segment (calculations.rs:217, 435)
 __global__ __launch_bounds__(256) void k_seg_finish_aabb(const uint32_t *__restrict__ aabb, const uint32_t *__restrict__ present, uint32_t nseg,
@@ -1198,8 +1243,15 @@ int32_t treee_segments_calculate_dev(treee_ctx *ctx, const float *d_xyz, const u
 		static_assert(sizeof(strides) == sizeof(runs), "one run length per level");
 		for (size_t l = 0; l < sizeof(strides) / sizeof(strides[0]); ++l) {
 			const uint32_t stride = strides[l], run = runs[l];
-			if (n && (stride == 1u || n >= 64ull * stride * run))
+			if (!(n && (stride == 1u || n >= 64ull * stride * run))) continue;
+			static const bool no_lds = getenv("TREEE_AABB_NO_LDS") != nullptr; // A/B and test hook: every level through the table in global memory
+			const uint64_t sample = div_up((uint64_t)n, (uint64_t)stride);
+			if (!no_lds && nseg <= AABB_LDS_SEGMENTS && sample >= (1ull << 20)) { // (the dense levels: the copy of the table has to pay)
+				const uint32_t grid = (uint32_t)std::min<uint64_t>(2ull * (uint64_t)ctx->num_cus, div_up(sample, (uint64_t)AABB_LDS_THREADS));
+				hipLaunchKernelGGL(k_seg_aabb_lds, dim3(grid), dim3(AABB_LDS_THREADS), 0, st, d_xyz, d_seg, n, nseg, stride, run, d_aabb, d_present);
+			} else {
 				hipLaunchKernelGGL(k_seg_aabb_direct, dim3(div_up(div_up(n, stride) + run, 256)), dim3(256), 0, st, d_xyz, d_seg, n, nseg, stride, run, d_aabb, d_present);
+			}
 		}
 	}
 	hipLaunchKernelGGL(k_seg_finish_aabb, dim3(gs), dim3(256), 0, st, d_aabb, d_present, nseg, d_seg_min, d_seg_max, d_nsl, d_err);
